@@ -1,0 +1,226 @@
+/*
+ * rt_mi355.h -- C ABI of librt_mi355.so: the MI355X (gfx950) replacement for the
+ * reference's ray-tracing compute dispatch.
+ *
+ * The reference has no FFI; its seam is the GL call sequence in
+ * ForwardShadingPipline::Render() (/root/reference/src/ForwardShadingPipeline.cpp:155-182):
+ * upload two SSBO byte arrays, set the uniforms, bind the cubemap, glDispatchCompute,
+ * glMemoryBarrier -- after which three textures hold the result.  Every entry point
+ * below names the reference call(s) it stands in for.  Plain pointers and sizes only;
+ * no torch / STL types cross this boundary.  All functions return 0 on success or a
+ * negative rt_status; nothing throws or aborts across the ABI.
+ *
+ * Threading: a context is owned by one thread at a time (the reference likewise has
+ * one GL context on one thread).  Multi-GPU = one context per device / process.
+ */
+#ifndef RT_MI355_H
+#define RT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OBJECT_STRIDE 176 /* sizeof(Object), /root/reference/src/Object.h:13-21 */
+#define RT_LIGHT_STRIDE 96   /* sizeof(Light),  /root/reference/src/Light.h:7-20  */
+#define RT_MAX_OBJECTS 512   /* LDS budget: 512 * (96 + 64) B = 80 KiB of the CU's 160 KiB */
+#define RT_MAX_LIGHTS 64
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,
+    RT_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error on create */
+    RT_ERR_HIP = -3,         /* a HIP call failed; see rt_last_error */
+    RT_ERR_TOO_LARGE = -4,   /* scene exceeds RT_MAX_OBJECTS / RT_MAX_LIGHTS */
+    RT_ERR_NO_SURFACES = -5, /* readback before any render */
+    RT_ERR_PARSE = -6
+} rt_status;
+
+/* Host mirror of the std430 records (offsets asserted below).
+ * The ABI takes raw bytes; these structs exist so C/C++ callers can fill them. */
+typedef struct rt_material { /* /root/reference/src/Material.h:11-23 */
+    int32_t type;            /* never read by the shader */
+    int32_t _pad0[3];
+    float albedo[3];
+    float metallic;
+    float roughness;
+    float diffuseStrength;
+    float ior;
+    float transparency;
+    float specular;          /* never read by the shader */
+    float subsurfaceScatter;
+    int32_t _pad1[2];
+    float subsurfaceColor[3];
+    float scatterDistance;
+} rt_material;
+
+typedef struct rt_object { /* /root/reference/src/Object.h:13-21 */
+    int32_t type;          /* 0 sphere, 1 plane */
+    int32_t _pad0[3];
+    float position[3];
+    float radius;
+    float normal[3];
+    int32_t _pad1;
+    float size[2];
+    int32_t _pad2[2];
+    rt_material material;
+    float boundsMin[3];
+    int32_t _pad3;
+    float boundsMax[3];
+    int32_t _pad4;
+} rt_object;
+
+typedef struct rt_light { /* /root/reference/src/Light.h:7-20 */
+    int32_t type;         /* 0 point, 1 directional, 2 area */
+    int32_t _pad0[3];
+    float position[3];
+    int32_t _pad1;
+    float direction[3];
+    int32_t _pad2;
+    float color[3];
+    float intensity;
+    float radius;         /* dead in the shader */
+    int32_t samples;      /* dead in the shader */
+    float shadowSoftness;
+    int32_t shadowType;   /* 0 none, 1 PCF, 2 PCSS */
+    int32_t pcfSamples;
+    float lightSize;
+    float angularRadius;  /* dead in the shader */
+    int32_t _pad3;
+} rt_light;
+
+/* The shader's uniform block (raytracingCs.glsl:72-89; uploaded by name at
+ * ForwardShadingPipeline.cpp:155-166) + imageSize(outputImage) (:200) + the render
+ * window.  Layout is shared with oracle/rt_oracle.h's orc_params. */
+typedef struct rt_params {
+    float camPos[3], camDir[3], camUp[3], camRight[3];
+    float fovDeg;         /* degrees; Camera::FOV */
+    float focalLength;    /* shader default 1.0 (never uploaded by the reference) */
+    float maxRayDistance; /* shader default 114514.0 (never uploaded) */
+    float noiseScale[2];  /* reference uploads 1/1024 */
+    int32_t frameCount;
+    int32_t useSkybox;
+    int32_t maxRayDepth;  /* #define MAX_RAY_DEPTH (3 as shipped) */
+    int32_t width, height;/* full image size: uv depends on it even for a window */
+    /* Window rendered by this call, in local-row space.  The output surfaces are
+     * regionW x regionH, row-major, row 0 = bottom (GL origin). */
+    int32_t x0, y0, regionW, regionH;
+    /* Interleaved row strips for multi-GPU tiling: local row ly is image row
+     * ((ly / stripRows) * stripCount + stripIndex) * stripRows + ly % stripRows.
+     * {1,1,0} is the identity (single GPU). */
+    int32_t stripRows, stripCount, stripIndex;
+    int32_t reserved[3];
+} rt_params;
+
+typedef struct rt_context rt_context;
+
+/* ---- lifetime: ForwardShadingPipline::Init() / dtor (ForwardShadingPipeline.cpp:6-20,
+ *      .h:38-48): shader "compile" + stream + timing events on HIP device deviceId. */
+int rt_create(rt_context **out, int deviceId);
+int rt_destroy(rt_context *ctx);
+
+/* ---- SSBO::update() + LightSSBO::update() (/root/reference/src/SSBO.h:16-23,
+ *      LightSSBO.h:16-25): copies nObj*176 + nLt*96 bytes; caller keeps ownership; cheap
+ *      enough to call every frame as the reference does (ImGUIManager.cpp:202,338). */
+int rt_set_scene(rt_context *ctx, const void *objects, int nObj, const void *lights, int nLt);
+
+/* ---- InitBlueNoiseTex (ForwardShadingPipeline.cpp:39-49): R8 texels, NEAREST/REPEAT.
+ *      NULL = the shipped behaviour (sampler reads 0). */
+int rt_set_noise(rt_context *ctx, const uint8_t *r8, int w, int h);
+
+/* ---- glBindTexture(GL_TEXTURE_CUBE_MAP, ...) (ForwardShadingPipeline.cpp:167-170):
+ *      6 faces (+X,-X,+Y,-Y,+Z,-Z) of size^2 RGB fp16, the format
+ *      TextureLoader.cpp:140-147 allocates.  NULL unbinds. */
+int rt_set_skybox(rt_context *ctx, const uint16_t *rgb16f, int size);
+
+/* ---- glDispatchCompute + glMemoryBarrier (ForwardShadingPipeline.cpp:175-180).
+ *      Asynchronous on the context's stream; renders into context-owned surfaces
+ *      (outputImage rgba32f, gPosition rgba32f, gNormal rgba16f; raytracingCs.glsl:61-63). */
+int rt_render(rt_context *ctx, const rt_params *p);
+
+/* Same, into caller-provided DEVICE surfaces (regionW*regionH*16, *16, *8 bytes) on a
+ * caller-provided hipStream_t (NULL = the context's stream).  Used for interop and for
+ * the multi-GPU strip buffers that RCCL gathers. */
+int rt_render_to(rt_context *ctx, const rt_params *p, void *dColor, void *dPosition,
+                 void *dNormal, void *hipStream);
+
+/* ---- glFinish (PerformanceProfiler.cpp:51). */
+int rt_sync(rt_context *ctx);
+
+/* ---- glGetTexImage equivalents: host copies of the last rt_render's surfaces.
+ *      Any pointer may be NULL. gNormal is 4 x fp16 per pixel (round-toward-zero). */
+int rt_readback(rt_context *ctx, float *gColor, float *gPosition, uint16_t *gNormal);
+
+/* Device pointers of the context-owned surfaces of the last rt_render. */
+int rt_get_surfaces(rt_context *ctx, void **dColor, void **dPosition, void **dNormal);
+
+/* ---- PerformanceProfiler Begin/EndGPUSection(RayTracing)
+ *      (ForwardShadingPipeline.cpp:172-182, PerformanceProfiler.cpp:23-31): duration of
+ *      the last render kernel from hipEvents on the launch stream; synchronises. */
+int rt_last_kernel_ms(rt_context *ctx, float *ms);
+
+/* Exact number of intersectObjects calls ("rays") for this frame,
+ * counted by an instrumented build of the same kernel.  Synchronises. */
+int rt_count_rays(rt_context *ctx, const rt_params *p, uint64_t *rays);
+
+/* Kernel variant: 0 = default.  Variants exist for A/B measurements only and all
+ * produce identical surfaces. */
+int rt_set_variant(rt_context *ctx, int variant);
+
+const char *rt_last_error(rt_context *ctx);
+
+/* ---- host-side feeders of the byte contract (no GPU needed) */
+/* GenerateAABBForObject (/root/reference/src/SceneIO.h:75-104), in place on n records. */
+int rt_generate_aabb(void *objects, int n);
+/* Camera::UpdateVectors (/root/reference/src/Camera.h:26-34). */
+int rt_camera_vectors(float yawDeg, float pitchDeg, float front[3], float right[3], float up[3]);
+/* SceneIO::Load's parser (/root/reference/src/SceneIO.h:108-122,145-186) on an in-memory
+ * text; fills up to maxObj/maxLt records (AABBs generated), returns counts. */
+int rt_scene_parse(const char *text, void *objects, int maxObj, int *nObj, void *lights,
+                   int maxLt, int *nLt);
+
+/* ---- multi-GPU strip helpers */
+/* Number of local rows a rank owns for interleaved strips. */
+int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);
+/* Rank-0 reassembly: src = stripCount packed strip buffers concatenated, each padded to
+ * maxLocalRows rows of `width` pixels of bytesPerPixel; dst = full width x height image.
+ * Device pointers; asynchronous on hipStream (NULL = the context's stream). */
+int rt_deinterleave(rt_context *ctx, const void *src, void *dst, int width, int height,
+                    int bytesPerPixel, int stripRows, int stripCount, int maxLocalRows,
+                    void *hipStream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L)
+#ifdef __cplusplus
+#define RT_SA(c, m) static_assert(c, m)
+#else
+#define RT_SA(c, m) _Static_assert(c, m)
+#endif
+RT_SA(sizeof(rt_material) == 80, "Material is 80 B");
+RT_SA(sizeof(rt_object) == RT_OBJECT_STRIDE, "Object stride is 176 B");
+RT_SA(sizeof(rt_light) == RT_LIGHT_STRIDE, "Light stride is 96 B");
+RT_SA(offsetof(rt_object, position) == 16 && offsetof(rt_object, radius) == 28, "Object.position/radius");
+RT_SA(offsetof(rt_object, normal) == 32 && offsetof(rt_object, size) == 48, "Object.normal/size");
+RT_SA(offsetof(rt_object, material) == 64, "Object.material");
+RT_SA(offsetof(rt_object, boundsMin) == 144 && offsetof(rt_object, boundsMax) == 160, "Object.bounds");
+RT_SA(offsetof(rt_material, albedo) == 16 && offsetof(rt_material, metallic) == 28, "Material.albedo/metallic");
+RT_SA(offsetof(rt_material, roughness) == 32 && offsetof(rt_material, diffuseStrength) == 36, "Material.roughness/diffuseStrength");
+RT_SA(offsetof(rt_material, ior) == 40 && offsetof(rt_material, transparency) == 44, "Material.ior/transparency");
+RT_SA(offsetof(rt_material, specular) == 48 && offsetof(rt_material, subsurfaceScatter) == 52, "Material.specular/sss");
+RT_SA(offsetof(rt_material, subsurfaceColor) == 64 && offsetof(rt_material, scatterDistance) == 76, "Material.sssColor/scatterDistance");
+RT_SA(offsetof(rt_light, position) == 16 && offsetof(rt_light, direction) == 32, "Light.position/direction");
+RT_SA(offsetof(rt_light, color) == 48 && offsetof(rt_light, intensity) == 60, "Light.color/intensity");
+RT_SA(offsetof(rt_light, radius) == 64 && offsetof(rt_light, samples) == 68, "Light.radius/samples");
+RT_SA(offsetof(rt_light, shadowSoftness) == 72 && offsetof(rt_light, shadowType) == 76, "Light.shadowSoftness/shadowType");
+RT_SA(offsetof(rt_light, pcfSamples) == 80 && offsetof(rt_light, lightSize) == 84, "Light.pcfSamples/lightSize");
+RT_SA(offsetof(rt_light, angularRadius) == 88, "Light.angularRadius");
+RT_SA(sizeof(rt_params) == 128, "rt_params is 128 B");
+#undef RT_SA
+#endif
+
+#endif /* RT_MI355_H */

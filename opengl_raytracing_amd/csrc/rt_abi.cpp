@@ -1,0 +1,410 @@
+// rt_abi.cpp -- implementation of the C ABI declared in include/rt_mi355.h: context,
+// device buffers, per-frame constants, launches, readback, timing.  Each entry point
+// stands in for a piece of the reference's dispatch site
+// (/root/reference/src/ForwardShadingPipeline.cpp:155-182); see the header for the map.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "rt_device.h"
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr, evScene = nullptr, evForeign = nullptr;
+    bool foreignPending = false;
+    bool timed = false;
+    // raw SSBO bytes + compiled scene
+    uint8_t *dObjects = nullptr, *dLights = nullptr;
+    size_t capObjects = 0, capLights = 0;
+    float4 *dCompiled = nullptr;
+    size_t capCompiledF4 = 0;
+    int nObj = 0, nLt = 0;
+    // double-buffered pinned staging so rt_set_scene never blocks on the GPU and the caller's
+    // bytes are consumed before it returns (glBufferData semantics)
+    uint8_t *hStage[2] = {nullptr, nullptr};
+    size_t capStage[2] = {0, 0};
+    hipEvent_t evStage[2] = {nullptr, nullptr};
+    bool stageUsed[2] = {false, false};
+    unsigned stageSeq = 0;
+    // textures
+    uint8_t *dNoise = nullptr;
+    int noiseW = 0, noiseH = 0;
+    uint16_t *dSky = nullptr;
+    int skySize = 0;
+    // context-owned output surfaces
+    float4 *dColor = nullptr, *dPos = nullptr;
+    uint2 *dNormal = nullptr;
+    size_t capPixels = 0;
+    int surfW = 0, surfH = 0;
+    unsigned long long *dRayCounter = nullptr;
+    int variant = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(rt_context *c, int code, const char *what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(c, call)                                        \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return fail(c, RT_ERR_HIP, #call, e_); \
+    } while (0)
+
+template <typename T>
+int ensure(rt_context *c, T **p, size_t *cap, size_t need) {
+    if (need <= *cap && *p) return RT_OK;
+    if (*p) HIP_TRY(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t n = need ? need : 1;
+    HIP_TRY(c, hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    return RT_OK;
+}
+
+// haltonSequence (/root/reference/shader/raytracingCs.glsl:278-288), host copy for the
+// per-depth bounce sample.
+float halton_host(int index, int base) {
+    float result = 0.0f;
+    float f = 1.0f / (float)base;
+    int i = index;
+    while (i > 0) {
+        result += f * (float)(i % base);
+        i = i / base;
+        f = f / (float)base;
+    }
+    return result;
+}
+
+// cosineWeightedHemisphere's local direction (:292-300) for a given (rand.x, rand.y)
+void hemi_local(float rx, float ry, float out[4]) {
+    const float PI_F = 3.14159265359f;
+    float phi = 2.0f * PI_F * rx;
+    float cosTheta = sqrtf(ry);
+    float sinTheta = sqrtf(1.0f - ry);
+    out[0] = sinTheta * cosf(phi);
+    out[1] = cosTheta;
+    out[2] = sinTheta * sinf(phi);
+    out[3] = 0.0f;
+}
+
+int validate_params(rt_context *c, const rt_params *p) {
+    if (!p) return fail(c, RT_ERR_INVALID_ARG, "params is NULL");
+    if (p->width <= 0 || p->height <= 0) return fail(c, RT_ERR_INVALID_ARG, "width/height must be positive");
+    if (p->regionW < 0 || p->regionH < 0 || p->x0 < 0 || p->y0 < 0)
+        return fail(c, RT_ERR_INVALID_ARG, "negative window");
+    if (p->stripRows <= 0 || p->stripCount <= 0 || p->stripIndex < 0 || p->stripIndex >= p->stripCount)
+        return fail(c, RT_ERR_INVALID_ARG, "bad strip mapping");
+    if (p->maxRayDepth < 0 || p->maxRayDepth > RT_MAX_DEPTH)
+        return fail(c, RT_ERR_INVALID_ARG, "maxRayDepth outside [0, 32]");
+    return RT_OK;
+}
+
+void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
+    memset(f, 0, sizeof *f);
+    f->p = *p;
+    f->nObj = c->nObj;
+    f->nLt = c->nLt;
+    f->noiseW = c->noiseW;
+    f->noiseH = c->noiseH;
+    f->skySize = c->skySize;
+    // generateCameraRay (:208-211): aspect, tan(radians(fov)*0.5); radians(x) = x*fl(pi/180)
+    float aspect = (float)p->width / (float)p->height;
+    float tanFov = tanf((p->fovDeg * 0.017453292519943295f) * 0.5f);
+    f->sx = aspect * tanFov * p->focalLength;
+    f->sy = tanFov * p->focalLength;
+    // hammersley(depth*64 + frameCount, 64) (:557, :311-313): same sample for every pixel
+    for (int d = 0; d < RT_MAX_DEPTH; d++) {
+        int hi = d * 64 + p->frameCount;
+        hemi_local((float)hi / 64.0f, halton_host(hi, 2), f->hemi[d]);
+    }
+    for (int i = 0; i < 4; i++) hemi_local((float)i / 4.0f, halton_host(i, 2), f->sssHemi[i]);   // :320
+}
+
+int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint2 *dNormal,
+           unsigned long long *counter, hipStream_t s, bool timed) {
+    RtFrame f;
+    build_frame(c, p, &f);
+    RtDeviceScene sc;
+    sc.compiled = c->dCompiled;
+    sc.noise = c->dNoise;
+    sc.sky = c->dSky;
+    if (!c->dCompiled) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene has not been called");
+    if (timed) HIP_TRY(c, hipEventRecord(c->evStart, s));
+    HIP_TRY(c, rt_launch_render(f, sc, dColor, dPos, dNormal, counter, c->variant, s));
+    if (timed) {
+        HIP_TRY(c, hipEventRecord(c->evStop, s));
+        c->timed = true;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(rt_context **out, int deviceId) {
+    if (!out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || deviceId < 0 || deviceId >= n) return RT_ERR_NO_DEVICE;
+    if (hipSetDevice(deviceId) != hipSuccess) return RT_ERR_NO_DEVICE;
+    rt_context *c = new (std::nothrow) rt_context();
+    if (!c) return RT_ERR_HIP;
+    c->device = deviceId;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evScene, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evForeign, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&c->dRayCounter, sizeof(unsigned long long)) != hipSuccess) {
+        rt_destroy(c);
+        return RT_ERR_HIP;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->evScene) (void)hipEventDestroy(c->evScene);
+    if (c->evForeign) (void)hipEventDestroy(c->evForeign);
+    for (int k = 0; k < 2; k++) {
+        if (c->evStage[k]) (void)hipEventDestroy(c->evStage[k]);
+        if (c->hStage[k]) (void)hipHostFree(c->hStage[k]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *lights, int nLt) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (nObj < 0 || nLt < 0 || (nObj > 0 && !objects) || (nLt > 0 && !lights))
+        return fail(c, RT_ERR_INVALID_ARG, "bad scene arguments");
+    if (nObj > RT_MAX_OBJECTS || nLt > RT_MAX_LIGHTS) return fail(c, RT_ERR_TOO_LARGE, "scene exceeds RT_MAX_OBJECTS/RT_MAX_LIGHTS");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, &c->dObjects, &c->capObjects, (size_t)nObj * RT_OBJECT_STRIDE))) return rc;
+    if ((rc = ensure(c, &c->dLights, &c->capLights, (size_t)nLt * RT_LIGHT_STRIDE))) return rc;
+    if ((rc = ensure(c, &c->dCompiled, &c->capCompiledF4, rt_compiled_f4(nObj, nLt)))) return rc;
+    if (c->foreignPending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evForeign, 0));
+        c->foreignPending = false;
+    }
+    const size_t objBytes = (size_t)nObj * RT_OBJECT_STRIDE, ltBytes = (size_t)nLt * RT_LIGHT_STRIDE;
+    const int k = (int)(c->stageSeq++ & 1u);
+    if (c->stageUsed[k]) HIP_TRY(c, hipEventSynchronize(c->evStage[k]));
+    if (objBytes + ltBytes > c->capStage[k]) {
+        if (c->hStage[k]) HIP_TRY(c, hipHostFree(c->hStage[k]));
+        c->hStage[k] = nullptr;
+        c->capStage[k] = 0;
+        size_t cap = objBytes + ltBytes < 65536 ? 65536 : objBytes + ltBytes;
+        HIP_TRY(c, hipHostMalloc((void **)&c->hStage[k], cap, hipHostMallocDefault));
+        c->capStage[k] = cap;
+    }
+    if (objBytes) memcpy(c->hStage[k], objects, objBytes);
+    if (ltBytes) memcpy(c->hStage[k] + objBytes, lights, ltBytes);
+    if (objBytes) HIP_TRY(c, hipMemcpyAsync(c->dObjects, c->hStage[k], objBytes, hipMemcpyHostToDevice, c->stream));
+    if (ltBytes) HIP_TRY(c, hipMemcpyAsync(c->dLights, c->hStage[k] + objBytes, ltBytes, hipMemcpyHostToDevice, c->stream));
+    if (!c->evStage[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evStage[k], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->evStage[k], c->stream));
+    c->stageUsed[k] = true;
+    HIP_TRY(c, rt_launch_compile_scene(c->dObjects, nObj, c->dLights, nLt, c->dCompiled, c->stream));
+    HIP_TRY(c, hipEventRecord(c->evScene, c->stream));   // foreign streams order behind this (rt_render_to)
+    c->nObj = nObj;
+    c->nLt = nLt;
+    return RT_OK;
+}
+
+int rt_set_noise(rt_context *c, const uint8_t *r8, int w, int h) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dNoise) { HIP_TRY(c, hipFree(c->dNoise)); c->dNoise = nullptr; }
+    c->noiseW = c->noiseH = 0;
+    if (!r8) return RT_OK;
+    if (w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID_ARG, "noise size must be positive");
+    HIP_TRY(c, hipMalloc((void **)&c->dNoise, (size_t)w * h));
+    HIP_TRY(c, hipMemcpy(c->dNoise, r8, (size_t)w * h, hipMemcpyHostToDevice));
+    c->noiseW = w;
+    c->noiseH = h;
+    return RT_OK;
+}
+
+int rt_set_skybox(rt_context *c, const uint16_t *rgb16f, int size) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dSky) { HIP_TRY(c, hipFree(c->dSky)); c->dSky = nullptr; }
+    c->skySize = 0;
+    if (!rgb16f) return RT_OK;
+    if (size <= 0) return fail(c, RT_ERR_INVALID_ARG, "skybox size must be positive");
+    size_t bytes = (size_t)6 * size * size * 3 * sizeof(uint16_t);
+    HIP_TRY(c, hipMalloc((void **)&c->dSky, bytes));
+    HIP_TRY(c, hipMemcpy(c->dSky, rgb16f, bytes, hipMemcpyHostToDevice));
+    c->skySize = size;
+    return RT_OK;
+}
+
+int rt_render(rt_context *c, const rt_params *p) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    int rc = validate_params(c, p);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t npx = (size_t)p->regionW * p->regionH;
+    if (npx > c->capPixels || !c->dColor) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->dColor) HIP_TRY(c, hipFree(c->dColor));
+        if (c->dPos) HIP_TRY(c, hipFree(c->dPos));
+        if (c->dNormal) HIP_TRY(c, hipFree(c->dNormal));
+        c->dColor = c->dPos = nullptr;
+        c->dNormal = nullptr;
+        c->capPixels = 0;
+        size_t n = npx ? npx : 1;
+        HIP_TRY(c, hipMalloc((void **)&c->dColor, n * sizeof(float4)));
+        HIP_TRY(c, hipMalloc((void **)&c->dPos, n * sizeof(float4)));
+        HIP_TRY(c, hipMalloc((void **)&c->dNormal, n * sizeof(uint2)));
+        c->capPixels = n;
+    }
+    c->surfW = p->regionW;
+    c->surfH = p->regionH;
+    return launch(c, p, c->dColor, c->dPos, c->dNormal, nullptr, c->stream, true);
+}
+
+int rt_render_to(rt_context *c, const rt_params *p, void *dColor, void *dPosition, void *dNormal, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    int rc = validate_params(c, p);
+    if (rc) return rc;
+    if (!dColor || !dPosition || !dNormal) return fail(c, RT_ERR_INVALID_ARG, "NULL device surface");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    if (s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->evScene, 0));
+    rc = launch(c, p, (float4 *)dColor, (float4 *)dPosition, (uint2 *)dNormal, nullptr, s, true);
+    if (rc == RT_OK && s != c->stream) {   // the next rt_set_scene must not overwrite the scene under this launch
+        HIP_TRY(c, hipEventRecord(c->evForeign, s));
+        c->foreignPending = true;
+    }
+    return rc;
+}
+
+int rt_sync(rt_context *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_readback(rt_context *c, float *gColor, float *gPosition, uint16_t *gNormal) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->dColor || c->surfW <= 0 || c->surfH <= 0) return fail(c, RT_ERR_NO_SURFACES, "no rendered surfaces");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    size_t npx = (size_t)c->surfW * c->surfH;
+    if (gColor) HIP_TRY(c, hipMemcpy(gColor, c->dColor, npx * sizeof(float4), hipMemcpyDeviceToHost));
+    if (gPosition) HIP_TRY(c, hipMemcpy(gPosition, c->dPos, npx * sizeof(float4), hipMemcpyDeviceToHost));
+    if (gNormal) HIP_TRY(c, hipMemcpy(gNormal, c->dNormal, npx * sizeof(uint2), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_surfaces(rt_context *c, void **dColor, void **dPosition, void **dNormal) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->dColor) return fail(c, RT_ERR_NO_SURFACES, "no rendered surfaces");
+    if (dColor) *dColor = c->dColor;
+    if (dPosition) *dPosition = c->dPos;
+    if (dNormal) *dNormal = c->dNormal;
+    return RT_OK;
+}
+
+int rt_last_kernel_ms(rt_context *c, float *ms) {
+    if (!c || !ms) return RT_ERR_INVALID_ARG;
+    if (!c->timed) return fail(c, RT_ERR_NO_SURFACES, "no timed render yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->evStop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->evStart, c->evStop));
+    return RT_OK;
+}
+
+int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) {
+    if (!c || !rays) return RT_ERR_INVALID_ARG;
+    int rc = validate_params(c, p);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t npx = (size_t)p->regionW * p->regionH;
+    float4 *col = nullptr, *pos = nullptr;
+    uint2 *nrm = nullptr;
+    size_t n = npx ? npx : 1;
+    HIP_TRY(c, hipMalloc((void **)&col, n * sizeof(float4)));
+    hipError_t e1 = hipMalloc((void **)&pos, n * sizeof(float4));
+    hipError_t e2 = hipMalloc((void **)&nrm, n * sizeof(uint2));
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+        rc = RT_OK;
+        if (hipMemsetAsync(c->dRayCounter, 0, sizeof(unsigned long long), c->stream) != hipSuccess) rc = RT_ERR_HIP;
+        if (!rc) rc = launch(c, p, col, pos, nrm, c->dRayCounter, c->stream, false);
+        unsigned long long v = 0;
+        if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess ||
+                    hipMemcpy(&v, c->dRayCounter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = fail(c, RT_ERR_HIP, "ray counter readback");
+        *rays = v;
+    } else {
+        rc = fail(c, RT_ERR_HIP, "hipMalloc (ray count scratch)", e1 != hipSuccess ? e1 : e2);
+    }
+    (void)hipFree(col);
+    if (pos) (void)hipFree(pos);
+    if (nrm) (void)hipFree(nrm);
+    return rc;
+}
+
+int rt_set_variant(rt_context *c, int variant) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    c->variant = variant;
+    return RT_OK;
+}
+
+const char *rt_last_error(rt_context *c) { return c ? c->err.c_str() : "NULL context"; }
+
+int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex) {
+    if (height < 0 || stripRows <= 0 || stripCount <= 0 || stripIndex < 0 || stripIndex >= stripCount) return RT_ERR_INVALID_ARG;
+    int nStrips = (height + stripRows - 1) / stripRows;
+    int rows = 0;
+    for (int s = stripIndex; s < nStrips; s += stripCount) {
+        int r0 = s * stripRows, r1 = r0 + stripRows;
+        if (r1 > height) r1 = height;
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+int rt_deinterleave(rt_context *c, const void *src, void *dst, int width, int height, int bytesPerPixel,
+                    int stripRows, int stripCount, int maxLocalRows, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!src || !dst || width <= 0 || height <= 0 || bytesPerPixel <= 0 || stripRows <= 0 || stripCount <= 0 || maxLocalRows <= 0)
+        return fail(c, RT_ERR_INVALID_ARG, "bad deinterleave arguments");
+    if (((size_t)width * bytesPerPixel) % 16 != 0) return fail(c, RT_ERR_INVALID_ARG, "row bytes must be a multiple of 16");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    HIP_TRY(c, rt_launch_deinterleave(src, dst, width, height, bytesPerPixel, stripRows, stripCount, maxLocalRows, s));
+    return RT_OK;
+}
+
+}  // extern "C"

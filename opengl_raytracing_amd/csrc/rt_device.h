@@ -1,0 +1,45 @@
+// rt_device.h -- shared declarations between the HIP kernels (rt_kernels.hip) and the
+// C-ABI implementation (rt_abi.cpp).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_mi355.h"
+
+#define RT_MAX_DEPTH 32      // per-depth bounce-sample table in kernarg memory
+#define RT_HALTON_N 64       // tabulated Halton indices (UI range of pcfSamples is 1..16)
+
+// "Compiled" scene record sizes, in float4 units.  See DESIGN.md "Data layout".
+#define RT_HOT_F4 6          // per object: AABB + shape, read for every ray
+#define RT_MAT_F4 4          // per object: material, read once per closest hit
+#define RT_LGT_F4 4          // per light
+
+// Per-launch constants, passed by value in kernarg memory (scalar loads, no staging).
+struct RtFrame {
+    rt_params p;
+    int32_t nObj, nLt;
+    int32_t noiseW, noiseH, skySize;
+    float sx, sy;                       // (aspect*tanFov)*focalLength, tanFov*focalLength
+    // cosineWeightedHemisphere's local direction for the bounce at each depth
+    // (identical for every pixel: hammersley(depth*64+frameCount, 64))
+    float hemi[RT_MAX_DEPTH][4];
+    float sssHemi[4][4];                // same for computeSubsurfaceScattering's 4 samples
+};
+
+struct RtDeviceScene {
+    const float4 *compiled;   // [nObj*RT_HOT_F4][nObj*RT_MAT_F4][nLt*RT_LGT_F4][halton2: 16][halton3: 16]
+    const uint8_t *noise;     // R8 texels or nullptr
+    const uint16_t *sky;      // 6*size*size*3 halfs or nullptr
+};
+
+static inline size_t rt_compiled_f4(int nObj, int nLt) {
+    return (size_t)nObj * (RT_HOT_F4 + RT_MAT_F4) + (size_t)nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
+}
+
+// Launch wrappers implemented in rt_kernels.hip
+hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint8_t *dLights, int nLt,
+                                   float4 *dCompiled, hipStream_t s);
+hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
+                            uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s);
+hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
+                                  int stripRows, int stripCount, int maxLocalRows, hipStream_t s);

@@ -1,0 +1,152 @@
+// rt_host.cpp -- host-side feeders of the byte contract (no GPU involved): the pieces of
+// the reference's C++ host that produce the bytes and uniforms the kernel trusts.
+//   rt_generate_aabb   <- GenerateAABBForObject   /root/reference/src/SceneIO.h:75-104
+//   rt_camera_vectors  <- Camera::UpdateVectors   /root/reference/src/Camera.h:26-34
+//   rt_scene_parse     <- SceneIO::Load + ParseObject/ParseLight  SceneIO.h:108-122,145-186
+// glm is not available here; the few glm calls used there are restated in fp32
+// (glm::normalize(v) = v * inversesqrt(dot(v,v)), dot = x*x + y*y + z*z, glm::radians(d) =
+// d * 0.01745329251994329576923690768489f).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <sstream>
+#include <string>
+
+#include "rt_mi355.h"
+
+namespace {
+
+struct f3 { float x, y, z; };
+inline f3 mk(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+inline f3 add(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline f3 mul(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+inline f3 crs(f3 a, f3 b) { return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+inline f3 nrm(f3 v) { float d = v.x * v.x + v.y * v.y + v.z * v.z; return mul(v, 1.0f / sqrtf(d)); }
+inline f3 ld(const float *p) { return mk(p[0], p[1], p[2]); }
+inline void st(float *p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+void aabb_one(rt_object *o) {
+    if (o->type == 0) {   // sphere: centre +- radius (SceneIO.h:76-80)
+        f3 p = ld(o->position), r = mk(o->radius, o->radius, o->radius);
+        st(o->boundsMin, sub(p, r));
+        st(o->boundsMax, add(p, r));
+    } else if (o->type == 1) {   // plane (SceneIO.h:81-103)
+        f3 n = ld(o->normal), right, forward;
+        if (fabsf(n.y) > 0.9f) {
+            right = mk(1, 0, 0);
+            forward = mk(0, 0, 1);
+        } else {
+            right = nrm(crs(n, mk(0, 1, 0)));
+            forward = nrm(crs(right, n));
+        }
+        f3 hx = mul(right, o->size[0] / 2.0f), hy = mul(forward, o->size[1] / 2.0f);
+        f3 p = ld(o->position);
+        f3 mn = sub(sub(p, hx), hy), mx = add(add(p, hx), hy);
+        mn = add(mn, mul(n, 0.01f));   // zero-thickness box shifted 1 cm along the normal (:97-102)
+        mx = add(mx, mul(n, 0.01f));
+        st(o->boundsMin, mn);
+        st(o->boundsMax, mx);
+    }
+}
+
+void default_object(rt_object *o) {   // Object.h:16-18, Material.h:12-22
+    memset(o, 0, sizeof *o);
+    o->radius = 1.0f;
+    o->normal[1] = 1.0f;
+    o->size[0] = o->size[1] = 1.0f;
+    o->material.type = 2;
+    o->material.albedo[0] = o->material.albedo[1] = o->material.albedo[2] = 1.0f;
+    o->material.roughness = 0.5f;
+    o->material.diffuseStrength = 0.0f;   // indeterminate upstream (Material.h:16); defined as 0 here
+    o->material.ior = 1.0f;
+    o->material.specular = 0.5f;
+    o->material.subsurfaceColor[0] = o->material.subsurfaceColor[1] = o->material.subsurfaceColor[2] = 1.0f;
+    o->material.scatterDistance = 0.1f;
+}
+
+void default_light(rt_light *l) {   // Light.h:8-19
+    memset(l, 0, sizeof *l);
+    l->direction[1] = -1.0f;
+    l->color[0] = l->color[1] = l->color[2] = 1.0f;
+    l->intensity = 1.0f;
+    l->radius = 0.5f;
+    l->samples = 4;
+    l->shadowSoftness = 1.0f;
+    l->shadowType = 1;
+    l->pcfSamples = 4;
+    l->lightSize = 1.0f;
+    l->angularRadius = 0.0f;   // indeterminate upstream (Light.h:19); dead in the shader
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_generate_aabb(void *objects, int n) {
+    if (n < 0 || (n > 0 && !objects)) return RT_ERR_INVALID_ARG;
+    rt_object *o = (rt_object *)objects;
+    for (int i = 0; i < n; i++) aabb_one(&o[i]);
+    return RT_OK;
+}
+
+int rt_camera_vectors(float yawDeg, float pitchDeg, float front[3], float right[3], float up[3]) {
+    if (!front || !right || !up) return RT_ERR_INVALID_ARG;
+    const float k = 0.01745329251994329576923690768489f;
+    float yaw = yawDeg * k, pitch = pitchDeg * k;
+    f3 f = nrm(mk(cosf(yaw) * cosf(pitch), sinf(pitch), sinf(yaw) * cosf(pitch)));
+    f3 r = nrm(crs(f, mk(0, 1, 0)));
+    f3 u = nrm(crs(r, f));
+    st(front, f);
+    st(right, r);
+    st(up, u);
+    return RT_OK;
+}
+
+int rt_scene_parse(const char *text, void *objects, int maxObj, int *nObj, void *lights, int maxLt, int *nLt) {
+    if (!text || !nObj || !nLt || maxObj < 0 || maxLt < 0) return RT_ERR_INVALID_ARG;
+    rt_object *objs = (rt_object *)objects;
+    rt_light *lts = (rt_light *)lights;
+    int no = 0, nl = 0;
+    std::istringstream all(text);
+    std::string line;
+    while (std::getline(all, line)) {
+        std::istringstream iss(line);
+        std::string kind;
+        iss >> kind;
+        if (kind == "OBJECT") {   // ParseObject (SceneIO.h:145-170)
+            rt_object o;
+            default_object(&o);
+            std::string typeStr, name;
+            iss >> typeStr >> name;
+            iss >> o.position[0] >> o.position[1] >> o.position[2];
+            o.type = (typeStr == "PLANE") ? 1 : 0;   // StringToObjectType: unknown -> SPHERE
+            iss >> o.radius >> o.normal[0] >> o.normal[1] >> o.normal[2] >> o.size[0] >> o.size[1];
+            int matType = 0;
+            iss >> matType;
+            o.material.type = matType;
+            iss >> o.material.albedo[0] >> o.material.albedo[1] >> o.material.albedo[2] >> o.material.metallic >>
+                o.material.roughness >> o.material.ior >> o.material.transparency >> o.material.specular;
+            aabb_one(&o);
+            if (no < maxObj && objs) objs[no] = o;
+            no++;
+        } else if (kind == "LIGHT") {   // ParseLight (SceneIO.h:172-186)
+            rt_light l;
+            default_light(&l);
+            std::string typeStr, name;
+            iss >> typeStr >> name;
+            l.type = (typeStr == "DIRECTIONAL") ? 1 : (typeStr == "AREA") ? 2 : 0;
+            iss >> l.position[0] >> l.position[1] >> l.position[2] >> l.direction[0] >> l.direction[1] >>
+                l.direction[2] >> l.color[0] >> l.color[1] >> l.color[2] >> l.intensity >> l.radius >> l.samples;
+            if (nl < maxLt && lts) lts[nl] = l;
+            nl++;
+        }
+    }
+    *nObj = no;
+    *nLt = nl;
+    if (no > maxObj || nl > maxLt) return RT_ERR_TOO_LARGE;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,702 @@
+// rt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the per-pixel ray
+// tracer.  What is computed follows /root/reference/shader/raytracingCs.glsl function by
+// function (cited below); how it is computed is MI355X-first:
+//
+//   * one 8x8-pixel tile per 64-lane wavefront, 4 waves (16x16 px) per workgroup;
+//   * the scene is "compiled" once per rt_set_scene into SoA-ish float4 records
+//     (hot = AABB + shape, cold = material, lights with per-light invariants folded,
+//     Halton tables) and staged ONCE PER WORKGROUP into LDS; the traversal loop reads it
+//     with wave-uniform (broadcast) ds_read_b128, never from HBM;
+//   * traversal carries a hit INDEX, the 64-byte material is fetched once per closest
+//     hit (the GLSL copies 80 B on every improvement -- same result);
+//   * shadow / PCSS-blocker rays use an any-hit traversal that leaves the loop as soon as
+//     the whole wavefront is occluded (exactly equivalent to the reference's closest-hit
+//     `t < lightDistance` test);
+//   * AABB misses skip the shape test wave-wide (exec-mask branch, s_cbranch_execz);
+//   * stores: one float4 per lane to gColor/gPosition (8 lanes = one 128-B line), one
+//     8-byte packed half4 (round-toward-zero) to gNormal.
+//
+// Arithmetic is fp32 in the reference's evaluation order (no FMA contraction: built with
+// -ffp-contract=off; IEEE divide/sqrt) so results are comparable bit-for-bit with the CPU
+// restatement in oracle/ wherever no transcendental is involved.
+#include "rt_device.h"
+
+#include <hip/hip_fp16.h>
+
+#define WAVE 64
+#define TILE 16           // workgroup tile edge in pixels
+#define BLOCK_THREADS 256
+
+namespace {
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 V3(float4 q) { return V3(q.x, q.y, q.z); }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 operator/(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ v3 splat(float s) { return V3(s, s, s); }
+// llvmpipe lowering: dot = (z*z + y*y) + x*x
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
+__device__ __forceinline__ float length(v3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// mix(): Mesa lowers the built-in context-dependently; the two shapes the shader uses were
+// probed bitwise on llvmpipe (tests/test_reference_probes.py):
+//   all-variable operands (:562)  -> a + t*(b-a);   constant first operand (:240) -> a*(1-t) + b*t
+__device__ __forceinline__ v3 mix_fast(v3 a, v3 b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ v3 mix_strict(v3 a, v3 b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
+__device__ __forceinline__ v3 refract(v3 I, v3 N, float eta) {
+    float d = dot(N, I);
+    float k = 1.0f - eta * (eta * (1.0f - d * d));
+    if (k < 0.0f) return V3(0.0f, 0.0f, 0.0f);
+    return I * eta - N * (eta * d + sqrtf(k));
+}
+__device__ __forceinline__ float fract(float x) { return x - floorf(x); }
+// pow(x, 5.0) (raytracingCs.glsl:222, :241): NaN for x < 0 as on the reference's GL
+// (exp2(5*log2 x)); exact-product form otherwise (<= 2 ulp; same three multiplies as the
+// oracle, and ~20x cheaper than powf on the VALU).
+__device__ __forceinline__ float pow5(float x) {
+    float x2 = x * x;
+    float r = (x2 * x2) * x;
+    return x < 0.0f ? __int_as_float(0x7fc00000) : r;
+}
+
+// Deterministic sin / exp in IEEE double +,* only (same source as oracle/rt_oracle.c, so the
+// two agree bit for bit; correctly rounded to fp32 on every sample tested).  Used once per
+// Russian-roulette decision (random(), :274) and once per SSS hit (:334) -- off the hot loop;
+// MI355X's full-rate fp64 makes this cheaper than an fp32 Payne-Hanek reduction.
+__device__ __forceinline__ float det_sinf(float xf) {
+    double x = (double)xf;
+    if (!(fabs(x) < 1.0e9)) return xf - xf;
+    double kd = rint(x * 0.63661977236758134308);
+    long long k = (long long)kd;
+    double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    double r2 = r * r;
+    double s = r + r * (r2 * (-1.66666666666666324348e-01 + r2 * (8.33333333332248946124e-03 + r2 * (-1.98412698298579493134e-04 +
+               r2 * (2.75573137070700676789e-06 + r2 * (-2.50507602534068634195e-08 + r2 * 1.58969099521155010221e-10))))));
+    double c = 1.0 + r2 * (-0.5 + r2 * (4.16666666666666019037e-02 + r2 * (-1.38888888888741095749e-03 +
+               r2 * (2.48015872894767294178e-05 + r2 * (-2.75573143513906633035e-07 + r2 * 2.08757232129817482790e-09)))));
+    double v = (k & 1) ? c : s;
+    if (k & 2) v = -v;
+    return (float)v;
+}
+
+__device__ __forceinline__ float det_expf(float xf) {
+    double x = (double)xf;
+    if (x != x) return xf;
+    if (x > 89.0) return __int_as_float(0x7f800000);
+    if (x < -104.0) return 0.0f;
+    double kd = rint(x * 1.44269504088896338700e+00);
+    double r = (x - kd * 6.93147180369123816490e-01) - kd * 1.90821492927058770002e-10;
+    double p = 1.0 + r * (1.0 + r * (0.5 + r * (1.66666666666666666667e-01 + r * (4.16666666666666666667e-02 +
+               r * (8.33333333333333333333e-03 + r * (1.38888888888888888889e-03 + r * (1.98412698412698412698e-04 +
+               r * (2.48015873015873015873e-05 + r * (2.75573192239858906526e-06 + r * 2.75573192239858906526e-07)))))))));
+    long long k = (long long)kd;
+    double sc = __longlong_as_double((long long)((unsigned long long)(k + 1023) << 52));
+    return (float)(p * sc);
+}
+
+constexpr float PI_F = 3.14159265359f;  // raytracingCs.glsl:6
+
+struct Ray { v3 o, d; };
+
+// LDS views of the compiled scene
+struct SceneLds {
+    const float4 *hot;     // nObj * RT_HOT_F4
+    const float4 *mat;     // nObj * RT_MAT_F4
+    const float4 *lgt;     // nLt  * RT_LGT_F4
+    const float *halton2;  // RT_HALTON_N
+    const float *halton3;  // RT_HALTON_N
+};
+
+// haltonSequence (raytracingCs.glsl:278-288); used by the scene compiler and as the
+// fallback for indices beyond the table.
+__device__ float halton_eval(int index, int base) {
+    float result = 0.0f;
+    float f = 1.0f / (float)base;
+    int i = index;
+    while (i > 0) {
+        result += f * (float)(i % base);
+        i = i / base;
+        f = f / (float)base;
+    }
+    return result;
+}
+
+// ---- traversal -------------------------------------------------------------------------
+// intersectAABB (:91-103) with invDir hoisted per ray (same IEEE value as the per-object
+// recomputation in the GLSL).
+__device__ __forceinline__ bool aabb_test(const Ray &r, v3 inv, float4 h0, float4 h1, float maxDist) {
+    float t0x = (h0.x - r.o.x) * inv.x, t1x = (h1.x - r.o.x) * inv.x;
+    float t0y = (h0.y - r.o.y) * inv.y, t1y = (h1.y - r.o.y) * inv.y;
+    float t0z = (h0.z - r.o.z) * inv.z, t1z = (h1.z - r.o.z) * inv.z;
+    float tMin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float tMax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    return (tMax >= tMin) && (tMin < maxDist) && (tMax > 0.0f);
+}
+
+// intersectSphere (:105-118) / intersectPlane (:120-153) on compiled records.
+// Returns true with t when the shape reports a hit (before the caller's t>0 && t<minT).
+__device__ __forceinline__ bool shape_test(const Ray &r, float a, const float4 *h, int type, float &t) {
+    if (type == 0) {
+        float4 h1 = h[1], h2 = h[2];
+        v3 oc = r.o - V3(h2);
+        float b = 2.0f * dot(oc, r.d);
+        float c = dot(oc, oc) - h1.w;               // h1.w = radius*radius
+        float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) return false;
+        t = (-b - sqrtf(disc)) / (2.0f * a);
+        return t > 0.0f;
+    } else if (type == 1) {
+        float4 h2 = h[2], h3 = h[3];
+        v3 n = V3(h3);
+        float denom = dot(n, r.d);
+        if (fabsf(denom) > 1e-6f) {
+            t = dot(V3(h2) - r.o, n) / denom;
+            if (t < 0.0f) return false;
+            float4 h4 = h[4], h5 = h[5];
+            v3 lo = (r.o + r.d * t) - V3(h2);
+            float x = dot(lo, V3(h4)), z = dot(lo, V3(h5));
+            if (fabsf(x) > h3.w || fabsf(z) > h4.w) return false;   // size/2.0 precomputed
+            return true;
+        }
+        return false;
+    }
+    return false;
+}
+
+// intersectObjects (:155-196), closest hit.  Returns the object index or -1; t = minT.
+template <bool COUNT>
+__device__ __forceinline__ int trace_closest(const SceneLds &sc, int nObj, const Ray &r, float maxDist,
+                                              float &tOut, unsigned &rays) {
+    if (COUNT) rays++;
+    v3 inv = V3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    float a = dot(r.d, r.d);
+    float minT = maxDist;
+    int hit = -1;
+    for (int i = 0; i < nObj; i++) {
+        const float4 *h = sc.hot + i * RT_HOT_F4;
+        float4 h0 = h[0], h1 = h[1];
+        if (aabb_test(r, inv, h0, h1, maxDist)) {
+            float t;
+            if (shape_test(r, a, h, __float_as_int(h0.w), t) && t > 0.0f && t < minT) {
+                minT = t;
+                hit = i;
+            }
+        }
+    }
+    tOut = minT;
+    return hit;
+}
+
+// Any-hit form for shadow / PCSS blocker rays: true iff some object is hit with
+// 0 < t < limit, limit = min(maxRayDistance, lightDistance) for point/area lights and
+// maxRayDistance for directional ones (exactly the reference's closest-hit test, A.1#14).
+// Lanes that found an occluder idle; the loop ends when the whole wave is done.
+template <bool COUNT>
+__device__ __forceinline__ bool trace_any(const SceneLds &sc, int nObj, const Ray &r, float maxDist,
+                                           float limit, unsigned &rays) {
+    if (COUNT) rays++;
+    v3 inv = V3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    float a = dot(r.d, r.d);
+    bool occ = false;
+    for (int i = 0; i < nObj; i++) {
+        const float4 *h = sc.hot + i * RT_HOT_F4;
+        float4 h0 = h[0], h1 = h[1];
+        if (!occ && aabb_test(r, inv, h0, h1, maxDist)) {
+            float t;
+            if (shape_test(r, a, h, __float_as_int(h0.w), t) && t > 0.0f && t < limit) occ = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;   // whole wavefront occluded
+    }
+    return occ;
+}
+
+// ---- textures --------------------------------------------------------------------------
+// texture(blueNoiseTex, (gid + frameCount) * noiseScale).r : R8, NEAREST, REPEAT (:513, :359)
+__device__ __forceinline__ float sample_noise(const RtFrame &f, const uint8_t *noise, unsigned gx, unsigned gy) {
+    if (!noise) return 0.0f;
+    float u = (float)(gx + (unsigned)f.p.frameCount) * f.p.noiseScale[0];
+    float v = (float)(gy + (unsigned)f.p.frameCount) * f.p.noiseScale[1];
+    u = fract(u); v = fract(v);
+    int ix = (int)floorf(u * (float)f.noiseW), iy = (int)floorf(v * (float)f.noiseH);
+    ix = min(max(ix, 0), f.noiseW - 1);
+    iy = min(max(iy, 0), f.noiseH - 1);
+    return (float)noise[(size_t)iy * f.noiseW + ix] * (1.0f / 255.0f);
+}
+
+__device__ __forceinline__ float half_bits_to_float(uint16_t h) {
+    return __half2float(__ushort_as_half(h));
+}
+
+// texture(skybox, d).rgb : LINEAR, CLAMP_TO_EDGE per face, non-seamless, RGB16F.  Manual fp32
+// bilinear (hardware filtering's 8-bit weights would break the 1e-4 tolerance; A.3).
+__device__ v3 sample_cube(const uint16_t *sky, int size, v3 d) {
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float sc, tc, ma;
+    if (ax >= ay && ax >= az) {
+        ma = ax;
+        if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; }
+    } else if (ay >= az) {
+        ma = ay;
+        if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; }
+    } else {
+        ma = az;
+        if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; }
+    }
+    float s = (sc / ma + 1.0f) / 2.0f, t = (tc / ma + 1.0f) / 2.0f;
+    float u = s * (float)size - 0.5f, v = t * (float)size - 0.5f;
+    float fu = floorf(u), fv = floorf(v);
+    float wu = u - fu, wv = v - fv;
+    int x0 = (int)fu, y0 = (int)fv;
+    int x1 = min(max(x0 + 1, 0), size - 1), y1 = min(max(y0 + 1, 0), size - 1);
+    x0 = min(max(x0, 0), size - 1); y0 = min(max(y0, 0), size - 1);
+    const uint16_t *f = sky + (size_t)face * size * size * 3;
+    const uint16_t *p00 = f + ((size_t)y0 * size + x0) * 3, *p10 = f + ((size_t)y0 * size + x1) * 3;
+    const uint16_t *p01 = f + ((size_t)y1 * size + x0) * 3, *p11 = f + ((size_t)y1 * size + x1) * 3;
+    float out[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float c00 = half_bits_to_float(p00[ch]), c10 = half_bits_to_float(p10[ch]);
+        float c01 = half_bits_to_float(p01[ch]), c11 = half_bits_to_float(p11[ch]);
+        float a = c00 + wu * (c10 - c00);
+        float b = c01 + wu * (c11 - c01);
+        out[ch] = a + wv * (b - a);
+    }
+    return V3(out[0], out[1], out[2]);
+}
+
+// imageStore to rgba16f rounds toward zero on the reference's GL (A.3).
+__device__ __forceinline__ unsigned f2h_rtz(float f) {
+    unsigned u = __float_as_uint(f);
+    unsigned s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (a == 0x7f800000u) ? (s | 0x7c00u) : (s | 0x7e00u | ((a >> 13) & 0x1ffu));
+    if (a >= 0x47800000u) return s | 0x7bffu;
+    if (a >= 0x38800000u) return s | ((a - 0x38000000u) >> 13);
+    if (a < 0x33800000u) return s;
+    unsigned e = a >> 23, m = (a & 0x7fffffu) | 0x800000u;
+    return s | (m >> (126u - e));
+}
+
+// ---- shading ---------------------------------------------------------------------------
+struct Mat {
+    v3 albedo; float metallic, roughness, diffuseStrength, ior, transparency;
+    v3 sssColor; float sss, scatterDistance;
+};
+
+__device__ __forceinline__ Mat load_mat(const SceneLds &sc, int idx) {
+    const float4 *m = sc.mat + idx * RT_MAT_F4;
+    float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+    Mat r;
+    r.albedo = V3(m0); r.metallic = m0.w;
+    r.roughness = m1.x; r.diffuseStrength = m1.y; r.ior = m1.z; r.transparency = m1.w;
+    r.sssColor = V3(m2); r.sss = m2.w; r.scatterDistance = m3.x;
+    return r;
+}
+
+// fresnelSchlick (:220-223); pow(x,2.0) folds to x*x on the reference's GL (A.3)
+__device__ __forceinline__ float fresnel_schlick(float cosTheta, float ior) {
+    float q = (1.0f - ior) / (1.0f + ior);
+    float r0 = q * q;
+    return r0 + (1.0f - r0) * pow5(1.0f - cosTheta);
+}
+
+// computePBR (:226-253)
+__device__ __forceinline__ v3 compute_pbr(const Mat &m, v3 N, v3 V, v3 L, v3 H, v3 radiance) {
+    float alpha = m.roughness * m.roughness;
+    float NdotH = fmaxf(dot(N, H), 0.0f);
+    // Mesa's NIR rewrites x*(a2-1)+1 as lerp(1, a2, x) = (1-x) + a2*x and PI*(i*i) as (PI*i)*i;
+    // both probed bitwise on llvmpipe.  The first matters: at grazing highlights the as-written
+    // form differs by up to 4e-4 rel in NDF.
+    float nh2 = NdotH * NdotH;
+    float inner = (1.0f - nh2) + (alpha * alpha) * nh2;
+    float NDF = alpha * alpha / ((PI_F * inner) * inner);
+    float rp1 = m.roughness + 1.0f;
+    float k = (rp1 * rp1) / 8.0f;
+    float NdotV = fmaxf(dot(N, V), 0.0f), NdotL = fmaxf(dot(N, L), 0.0f);
+    float G = NdotV / (NdotV * (1.0f - k) + k);
+    G *= NdotL / (NdotL * (1.0f - k) + k);
+    v3 F0 = mix_strict(splat(0.04f), m.albedo, m.metallic);
+    float p5 = pow5(1.0f - fmaxf(dot(H, V), 0.0f));
+    v3 F = F0 + (splat(1.0f) - F0) * p5;
+    v3 numerator = F * (NDF * G);
+    float denominator = 4.0f * NdotV * NdotL;
+    v3 specular = numerator / fmaxf(denominator, 0.001f);
+    v3 kD = (splat(1.0f) - F) * (1.0f - m.metallic);
+    v3 diffuse = (kD * m.albedo) / PI_F;
+    return ((diffuse + specular) * radiance) * NdotL;
+}
+
+// cosineWeightedHemisphere (:291-308) with the per-depth local direction h precomputed on
+// the host (it depends only on depth and frameCount).
+__device__ __forceinline__ v3 hemisphere_dir(v3 h, v3 n) {
+    v3 tangent = normalize(cross(n, V3(0.0f, 1.0f, 1.0f)));
+    v3 bitangent = cross(n, tangent);
+    return normalize((tangent * h.x + bitangent * h.z) + n * h.y);
+}
+
+__device__ __forceinline__ float halton_lookup(const float *table, int i, int base) {
+    return (i < RT_HALTON_N) ? table[i] : halton_eval(i, base);
+}
+
+// pcfShadow (:342-397)
+template <bool COUNT>
+__device__ __forceinline__ float pcf_shadow(const SceneLds &sc, const RtFrame &f, v3 origin, int ltype,
+                                             int pcfSamples, float filterSize, v3 lightDir, float limit,
+                                             float jitterR, unsigned &rays) {
+    float shadow = 0.0f;
+    v3 tangent = normalize(cross(lightDir, V3(0.0f, 1.0f, 0.0f)));
+    v3 bitangent = cross(lightDir, tangent);
+    for (int i = 0; i < pcfSamples; i++) {
+        float rx = fract(halton_lookup(sc.halton2, i, 2) + jitterR);
+        float ry = fract(halton_lookup(sc.halton3, i, 3) + 0.0f);
+        v3 jd = (lightDir + (tangent * rx) * filterSize) + (bitangent * ry) * filterSize;
+        if (ltype != 1) jd = normalize(jd);
+        Ray sr; sr.o = origin; sr.d = jd;
+        bool occ = trace_any<COUNT>(sc, f.nObj, sr, f.p.maxRayDistance, limit, rays);
+        shadow += occ ? 0.0f : 1.0f;
+    }
+    return shadow / (float)pcfSamples;
+}
+
+// pcssShadow (:400-440): 16 blocker-search rays; any blocker -> plain PCF (penumbra size is dead)
+template <bool COUNT>
+__device__ __forceinline__ float pcss_shadow(const SceneLds &sc, const RtFrame &f, v3 origin, int ltype,
+                                              int pcfSamples, float filterSize, float searchSize, v3 lightDir,
+                                              float limit, float jitterR, unsigned &rays) {
+    bool any = false;
+    for (int i = 0; i < 16; i++) {
+        float rr = sc.halton3[i] * 2.0f - 1.0f;
+        v3 sd = (lightDir + splat(rr * searchSize)) + splat(rr * searchSize);
+        Ray sr; sr.o = origin; sr.d = normalize(sd);
+        any |= trace_any<COUNT>(sc, f.nObj, sr, f.p.maxRayDistance, limit, rays);
+    }
+    if (!any) return 1.0f;
+    return pcf_shadow<COUNT>(sc, f, origin, ltype, pcfSamples, filterSize, lightDir, limit, jitterR, rays);
+}
+
+// computeSubsurfaceScattering (:316-339)
+template <bool COUNT>
+__device__ v3 compute_sss(const SceneLds &sc, const RtFrame &f, v3 P, v3 N, const Mat &m, unsigned &rays) {
+    v3 sss = V3(0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < 4; i++) {
+        Ray r;
+        r.o = P + N * 0.001f;
+        r.d = hemisphere_dir(V3(f.sssHemi[i][0], f.sssHemi[i][1], f.sssHemi[i][2]), N);
+        float t;
+        int idx = trace_closest<COUNT>(sc, f.nObj, r, f.p.maxRayDistance, t, rays);
+        if (idx >= 0) {
+            float att = det_expf(-t / m.scatterDistance);
+            sss = sss + V3(sc.mat[idx * RT_MAT_F4]) * att;
+        }
+    }
+    return ((sss * m.sssColor) * m.sss) / 4.0f;
+}
+
+// computeLighting (:457-507)
+template <bool COUNT>
+__device__ __forceinline__ v3 compute_lighting(const SceneLds &sc, const RtFrame &f, v3 P, v3 N, const Mat &m,
+                                                v3 V, float jitterR, unsigned &rays) {
+    v3 Lo = V3(0.0f, 0.0f, 0.0f);
+    v3 shadowOrigin = P + N * 0.001f;     // :381, :412
+    for (int i = 0; i < f.nLt; i++) {
+        const float4 *lr = sc.lgt + i * RT_LGT_F4;
+        float4 l0 = lr[0], l1 = lr[1], l2 = lr[2], l3 = lr[3];
+        int ltype = __float_as_int(l0.w);
+        v3 lightDir = V3(0.0f, 0.0f, 0.0f);
+        float attenuation = 1.0f, lightDistance = 0.0f;
+        if (ltype == 0) {
+            lightDir = V3(l0) - P;
+            lightDistance = length(lightDir);
+            attenuation = 1.0f / (1.0f + 0.1f * lightDistance + 0.01f * lightDistance * lightDistance);
+            lightDir = normalize(lightDir);
+        } else if (ltype == 1) {
+            lightDir = V3(l1);             // normalize(-direction), folded by the scene compiler
+            lightDistance = 1e6f;
+        } else if (ltype == 2) {
+            lightDir = V3(l0) - P;
+            // lightDistance*lightDistance = sqrt(q)*sqrt(q) folds to |q| on the reference's GL
+            float q = dot(lightDir, lightDir);
+            lightDistance = length(lightDir);
+            lightDir = normalize(lightDir);
+            attenuation = 1.0f / fabsf(q);
+            float lc = fmaxf(dot(lightDir, V3(l1)), 0.0f);   // l1 = normalize(direction)
+            attenuation *= lc;
+        }
+        int shadowType = __float_as_int(l3.x), pcfSamples = __float_as_int(l3.y);
+        float shadowFactor = 1.0f;
+        if (shadowType != 0) {
+            // any-hit limit: closest t < lightDistance for point/area lights (:390-392, :421-423)
+            float limit = (ltype == 1) ? f.p.maxRayDistance : fminf(f.p.maxRayDistance, lightDistance);
+            // NaN lightDistance: the reference's `t < NaN` is false -> never occluded
+            if (ltype != 1 && !(lightDistance == lightDistance)) limit = -1.0f;
+            if (shadowType == 1)
+                shadowFactor = pcf_shadow<COUNT>(sc, f, shadowOrigin, ltype, pcfSamples, l2.w, lightDir, limit, jitterR, rays);
+            else if (shadowType == 2)
+                shadowFactor = pcss_shadow<COUNT>(sc, f, shadowOrigin, ltype, pcfSamples, l2.w, l3.z, lightDir, limit, jitterR, rays);
+            else
+                shadowFactor = 0.0f;       // calculateShadow's `float shadow = 0.0` fall-through (:445)
+        }
+        v3 L = normalize(lightDir);
+        v3 H = normalize(V + L);
+        v3 radiance = (V3(l2) * attenuation) * l1.w;
+        Lo = Lo + compute_pbr(m, N, V, L, H, radiance) * shadowFactor;
+    }
+    if (m.sss > 0.0f) Lo = Lo + compute_sss<COUNT>(sc, f, P, N, m, rays);
+    return Lo;
+}
+
+// calculateRefraction (:256-270)
+__device__ __forceinline__ v3 calc_refraction(const Ray &r, v3 N, float ior) {
+    bool entering = dot(r.d, N) < 0.0f;
+    float eta = entering ? (1.0f / ior) : ior;
+    v3 normal = entering ? N : -N;
+    v3 rd = refract(normalize(r.d), normal, eta);
+    if (dot(rd, rd) < 0.001f) rd = reflect(r.d, normal);
+    return rd;
+}
+
+// random (:273-275)
+__device__ __forceinline__ float random2(float sx, float sy) {
+    float d = sy * 78.233f + sx * 12.9898f;
+    return fract(det_sinf(d) * 43758.5453123f);
+}
+
+}  // namespace
+
+// =========================================================================================
+// Scene compiler: raw std430 bytes -> compiled float4 records (one launch per rt_set_scene).
+// =========================================================================================
+__global__ void rt_compile_scene_kernel(const uint8_t *objects, int nObj, const uint8_t *lights, int nLt,
+                                        float4 *out) {
+    float4 *hot = out;
+    float4 *mat = hot + (size_t)nObj * RT_HOT_F4;
+    float4 *lgt = mat + (size_t)nObj * RT_MAT_F4;
+    float *h2 = (float *)(lgt + (size_t)nLt * RT_LGT_F4);
+    float *h3 = h2 + RT_HALTON_N;
+    for (int i = threadIdx.x; i < nObj; i += blockDim.x) {
+        const float *o = (const float *)(objects + (size_t)i * RT_OBJECT_STRIDE);   // offsets: Appendix B
+        int type = ((const int *)o)[0];
+        v3 pos = V3(o[4], o[5], o[6]);
+        float radius = o[7];
+        v3 n = V3(o[8], o[9], o[10]);
+        float sx = o[12], sy = o[13];
+        // plane basis of intersectPlane (:129-138): constant per object
+        v3 right;
+        if (fabsf(n.y) > 0.9f) right = normalize(cross(n, V3(0.0f, 0.0f, 1.0f)));
+        else right = normalize(cross(n, V3(0.0f, 1.0f, 0.0f)));
+        v3 forward = normalize(cross(right, n));
+        float4 *h = hot + (size_t)i * RT_HOT_F4;
+        h[0] = make_float4(o[36], o[37], o[38], __int_as_float(type));   // bounds.min @144
+        h[1] = make_float4(o[40], o[41], o[42], radius * radius);         // bounds.max @160
+        h[2] = make_float4(pos.x, pos.y, pos.z, radius);
+        h[3] = make_float4(n.x, n.y, n.z, sx / 2.0f);
+        h[4] = make_float4(right.x, right.y, right.z, sy / 2.0f);
+        h[5] = make_float4(forward.x, forward.y, forward.z, 0.0f);
+        float4 *m = mat + (size_t)i * RT_MAT_F4;
+        m[0] = make_float4(o[20], o[21], o[22], o[23]);   // albedo @80, metallic @92
+        m[1] = make_float4(o[24], o[25], o[26], o[27]);   // roughness, diffuseStrength, ior, transparency
+        m[2] = make_float4(o[32], o[33], o[34], o[29]);   // subsurfaceColor @128, subsurfaceScatter @116
+        m[3] = make_float4(o[35], 0.0f, 0.0f, 0.0f);      // scatterDistance @140
+    }
+    for (int i = threadIdx.x; i < nLt; i += blockDim.x) {
+        const float *l = (const float *)(lights + (size_t)i * RT_LIGHT_STRIDE);
+        int type = ((const int *)l)[0];
+        v3 dir = V3(l[8], l[9], l[10]);
+        v3 dn = (type == 1) ? normalize(-dir) : normalize(dir);   // :475 / :486
+        float4 *r = lgt + (size_t)i * RT_LGT_F4;
+        r[0] = make_float4(l[4], l[5], l[6], __int_as_float(type));
+        r[1] = make_float4(dn.x, dn.y, dn.z, l[15]);                 // intensity @60
+        r[2] = make_float4(l[12], l[13], l[14], l[18] * 0.005f);     // color @48, filterSize (:364)
+        r[3] = make_float4(__int_as_float(((const int *)l)[19]),     // shadowType @76
+                           __int_as_float(((const int *)l)[20]),     // pcfSamples @80
+                           l[21] * 0.1f, 0.0f);                      // searchSize (:404)
+    }
+    for (int i = threadIdx.x; i < RT_HALTON_N; i += blockDim.x) {
+        h2[i] = halton_eval(i, 2);
+        h3[i] = halton_eval(i, 3);
+    }
+}
+
+// =========================================================================================
+// Render kernel: main() of raytracingCs.glsl (:509-584), one lane per pixel.
+// =========================================================================================
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK_THREADS) void rt_render_kernel(const RtFrame f, const RtDeviceScene dsc,
+                                                                  float4 *__restrict__ gColor,
+                                                                  float4 *__restrict__ gPosition,
+                                                                  uint2 *__restrict__ gNormal,
+                                                                  unsigned long long *rayCounter) {
+    extern __shared__ float4 lds[];
+    // ---- stage the compiled scene into LDS once per workgroup (coalesced 16-B copies)
+    const int nF4 = f.nObj * (RT_HOT_F4 + RT_MAT_F4) + f.nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
+    for (int i = threadIdx.x; i < nF4; i += BLOCK_THREADS) lds[i] = dsc.compiled[i];
+    __syncthreads();
+    SceneLds sc;
+    sc.hot = lds;
+    sc.mat = sc.hot + f.nObj * RT_HOT_F4;
+    sc.lgt = sc.mat + f.nObj * RT_MAT_F4;
+    sc.halton2 = (const float *)(sc.lgt + f.nLt * RT_LGT_F4);
+    sc.halton3 = sc.halton2 + RT_HALTON_N;
+
+    // ---- lane -> pixel: wave w owns the 8x8 tile (w&1, w>>1) of the 16x16 workgroup tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
+    const int j = blockIdx.y * TILE + (wave >> 1) * 8 + (lane >> 3);
+    unsigned rays = 0;
+    if (i < f.p.regionW && j < f.p.regionH) {
+    const int gxI = f.p.x0 + i;
+    const int ly = f.p.y0 + j;
+    const int gyI = ((ly / f.p.stripRows) * f.p.stripCount + f.p.stripIndex) * f.p.stripRows + ly % f.p.stripRows;
+    const size_t outIdx = (size_t)j * f.p.regionW + i;
+    if (gxI >= f.p.width || gyI >= f.p.height) {   // outside the image: GL discards the imageStore
+        gColor[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        gPosition[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        gNormal[outIdx] = make_uint2(0u, 0u);
+    } else {
+    const unsigned gx = (unsigned)gxI, gy = (unsigned)gyI;
+
+    // jitter (:512-514): .x from the R8 sample, .y of an R8 texture is 0 -> -1 (A.1#3)
+    const float nz = sample_noise(f, dsc.noise, gx, gy);
+    const float jx = nz * 2.0f - 1.0f, jy = 0.0f * 2.0f - 1.0f;
+
+    // generateCameraRay (:198-217)
+    Ray ray;
+    {
+        float ux = (((float)gxI + 0.5f) + jx) / (float)f.p.width;
+        float uy = (((float)gyI + 0.5f) + jy) / (float)f.p.height;
+        ux = ux * 2.0f - 1.0f;
+        uy = uy * 2.0f - 1.0f;
+        ux *= f.sx;
+        uy *= f.sy;
+        v3 cd = V3(f.p.camDir[0], f.p.camDir[1], f.p.camDir[2]);
+        v3 cr = V3(f.p.camRight[0], f.p.camRight[1], f.p.camRight[2]);
+        v3 cu = V3(f.p.camUp[0], f.p.camUp[1], f.p.camUp[2]);
+        ray.o = V3(f.p.camPos[0], f.p.camPos[1], f.p.camPos[2]);
+        ray.d = normalize((cd + cr * ux) + cu * uy);
+    }
+
+    v3 finalColor = V3(0.0f, 0.0f, 0.0f), throughput = V3(1.0f, 1.0f, 1.0f);
+    v3 P = V3(0.0f, 0.0f, 0.0f), N = V3(0.0f, 0.0f, 0.0f);   // undefined locals read as zero (A.3)
+
+    for (int depth = 0; depth < f.p.maxRayDepth; ++depth) {
+        float t;
+        int idx = trace_closest<COUNT>(sc, f.nObj, ray, f.p.maxRayDistance, t, rays);
+        if (idx < 0) {
+            if (f.p.useSkybox && dsc.sky) finalColor = finalColor + throughput * sample_cube(dsc.sky, f.skySize, ray.d);
+            else finalColor = finalColor + throughput * V3(0.0f, 0.0f, 0.0f);
+            break;
+        }
+        // hit normal (:187-191): sphere = normalize(hit - centre); plane = raw normal
+        {
+            const float4 *h = sc.hot + idx * RT_HOT_F4;
+            if (__float_as_int(h[0].w) == 0) N = normalize((ray.o + ray.d * t) - V3(h[2]));
+            else N = V3(h[3]);
+        }
+        const Mat m = load_mat(sc, idx);
+        P = ray.o + ray.d * t;
+        v3 V = normalize(-ray.d);
+        v3 Lo = compute_lighting<COUNT>(sc, f, P, N, m, V, nz, rays);
+        finalColor = finalColor + throughput * Lo;
+
+        if (depth > 2) {   // Russian roulette (:544-549)
+            float dw = length(m.albedo) * m.diffuseStrength;
+            float cp = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * 0.95f + dw, 0.99f);
+            float rnd = random2((float)(gx + (unsigned)depth), (float)(gy + (unsigned)depth));
+            if (rnd > cp) break;
+            throughput = throughput / cp;
+        }
+        float F = fresnel_schlick(fmaxf(dot(V, N), 0.0f), m.ior);
+        if (m.diffuseStrength > 0.0f) {          // :555-567
+            const int dd = depth < RT_MAX_DEPTH ? depth : RT_MAX_DEPTH - 1;
+            v3 sd = reflect(ray.d, N);
+            v3 hd = hemisphere_dir(V3(f.hemi[dd][0], f.hemi[dd][1], f.hemi[dd][2]), N);
+            ray.d = normalize(mix_fast(sd, hd, m.roughness));
+            ray.o = P + N * 0.001f;
+            throughput = throughput * (m.albedo * m.diffuseStrength);
+        } else if (m.transparency > 0.0f) {      // :568-571
+            ray.d = calc_refraction(ray, N, m.ior);
+            ray.o = P - N * 0.001f;
+            throughput = throughput * ((m.albedo * (1.0f - F)) * m.transparency);
+        } else {                                  // :572-576
+            ray.d = reflect(ray.d, N);
+            ray.o = P + N * 0.001f;
+            throughput = throughput * (m.albedo * F);
+        }
+    }
+
+    gColor[outIdx] = make_float4(finalColor.x, finalColor.y, finalColor.z, 1.0f);
+    gPosition[outIdx] = make_float4(P.x, P.y, P.z, 1.0f);
+    gNormal[outIdx] = make_uint2(f2h_rtz(N.x) | (f2h_rtz(N.y) << 16), f2h_rtz(N.z) | (0x3c00u << 16));
+
+    }   // inside the image
+    }   // inside the window
+
+    if (COUNT) {   // instrumented build only: block-level sum in LDS, one global atomic per workgroup
+        unsigned long long *blockRays = (unsigned long long *)(lds + nF4);
+        if (threadIdx.x == 0) *blockRays = 0ull;
+        __syncthreads();
+        atomicAdd(blockRays, (unsigned long long)rays);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(rayCounter, *blockRays);
+    }
+}
+
+// =========================================================================================
+// Rank-0 reassembly of gathered interleaved strips (multi-GPU): pure copy kernel, 16 B/lane.
+// =========================================================================================
+__global__ void rt_deinterleave_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int rowU4,
+                                       int height, int stripRows, int stripCount, int maxLocalRows) {
+    const size_t total = (size_t)rowU4 * height;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(k / rowU4), c = (int)(k % rowU4);
+        int strip = y / stripRows;
+        int rank = strip % stripCount, localStrip = strip / stripCount;
+        int ly = localStrip * stripRows + y % stripRows;
+        dst[k] = src[((size_t)rank * maxLocalRows + ly) * rowU4 + c];
+    }
+}
+
+// =========================================================================================
+// Launch wrappers
+// =========================================================================================
+hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint8_t *dLights, int nLt,
+                                   float4 *dCompiled, hipStream_t s) {
+    hipLaunchKernelGGL(rt_compile_scene_kernel, dim3(1), dim3(256), 0, s, dObjects, nObj, dLights, nLt, dCompiled);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
+                            uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s) {
+    (void)variant;
+    if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
+    dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
+    size_t ldsBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
+    if (dRayCounter)
+        hipLaunchKernelGGL(rt_render_kernel<true>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+    else
+        hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
+                                  int stripRows, int stripCount, int maxLocalRows, hipStream_t s) {
+    size_t rowBytes = (size_t)width * bytesPerPixel;
+    if (rowBytes % 16 != 0) return hipErrorInvalidValue;
+    int rowU4 = (int)(rowBytes / 16);
+    size_t total = (size_t)rowU4 * height;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rt_deinterleave_kernel, dim3(blocks), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst, rowU4,
+                       height, stripRows, stripCount, maxLocalRows);
+    return hipGetLastError();
+}

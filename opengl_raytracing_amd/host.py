@@ -1,0 +1,230 @@
+"""ctypes binding of librt_mi355.so -- the Python-side mirror of the reference's dispatch
+site (/root/reference/src/ForwardShadingPipeline.cpp:155-182).
+
+``RayTracer`` plays the part of ``ForwardShadingPipline``'s ray-tracing members:
+
+=====================================  ====================================================
+reference (C++ / GL)                   here
+=====================================  ====================================================
+``ssbo.update(); lightSSBO.update()``  ``RayTracer.set_scene(objects, lights)``
+``raytracingShader.setXxx(...)``       fields of ``RtParams`` (layout.make_params)
+``glBindTexture(CUBE_MAP, ...)``       ``RayTracer.set_skybox(faces)``
+blue-noise texture                     ``RayTracer.set_noise(r8)``
+``glDispatchCompute + glMemoryBarrier````RayTracer.render(params)``
+``glGetTexImage``                      ``RayTracer.readback()``
+``gProfiler`` RayTracing stage         ``RayTracer.last_kernel_ms()``
+=====================================  ====================================================
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the calls
+raise ``RtError``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import layout as L
+
+_LIB = None
+
+EXPORTS = [
+    "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
+    "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
+    "rt_count_rays", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
+    "rt_scene_parse", "rt_strip_local_rows", "rt_deinterleave",
+]
+
+RT_OK = 0
+STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARG", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP",
+                -4: "RT_ERR_TOO_LARGE", -5: "RT_ERR_NO_SURFACES", -6: "RT_ERR_PARSE"}
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+
+
+def load_library(build_if_missing=True):
+    """dlopen the in-tree librt_mi355.so (building it first if asked and absent)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RtError(-2, f"{path} not built (run python -m opengl_raytracing_amd.build)")
+        _build.build_library()
+    lib = ctypes.CDLL(path)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    P = ctypes.POINTER
+    lib.rt_create.argtypes = [P(vp), ci]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_set_scene.argtypes = [vp, vp, ci, vp, ci]
+    lib.rt_set_noise.argtypes = [vp, vp, ci, ci]
+    lib.rt_set_skybox.argtypes = [vp, vp, ci]
+    lib.rt_render.argtypes = [vp, P(L.RtParams)]
+    lib.rt_render_to.argtypes = [vp, P(L.RtParams), vp, vp, vp, vp]
+    lib.rt_sync.argtypes = [vp]
+    lib.rt_readback.argtypes = [vp, vp, vp, vp]
+    lib.rt_get_surfaces.argtypes = [vp, P(vp), P(vp), P(vp)]
+    lib.rt_last_kernel_ms.argtypes = [vp, P(ctypes.c_float)]
+    lib.rt_count_rays.argtypes = [vp, P(L.RtParams), P(ctypes.c_uint64)]
+    lib.rt_set_variant.argtypes = [vp, ci]
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = ctypes.c_char_p
+    lib.rt_generate_aabb.argtypes = [vp, ci]
+    lib.rt_camera_vectors.argtypes = [ctypes.c_float, ctypes.c_float, P(ctypes.c_float), P(ctypes.c_float), P(ctypes.c_float)]
+    lib.rt_scene_parse.argtypes = [ctypes.c_char_p, vp, ci, P(ci), vp, ci, P(ci)]
+    lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
+    lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    for name in EXPORTS:
+        if name != "rt_last_error":
+            getattr(lib, name).restype = ci
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+# ---- host-side feeders (no GPU) ------------------------------------------------------------
+def generate_aabb(objects):
+    """GenerateAABBForObject (/root/reference/src/SceneIO.h:75-104), in place."""
+    assert objects.dtype == L.OBJECT_DTYPE and objects.flags["C_CONTIGUOUS"]
+    rc = load_library().rt_generate_aabb(_ptr(objects), len(objects))
+    if rc:
+        raise RtError(rc, "rt_generate_aabb")
+    return objects
+
+
+def camera_vectors(yaw_deg=-90.0, pitch_deg=0.0):
+    """Camera::UpdateVectors (/root/reference/src/Camera.h:26-34) -> (front, right, up)."""
+    f, r, u = (ctypes.c_float * 3)(), (ctypes.c_float * 3)(), (ctypes.c_float * 3)()
+    rc = load_library().rt_camera_vectors(yaw_deg, pitch_deg, f, r, u)
+    if rc:
+        raise RtError(rc, "rt_camera_vectors")
+    return tuple(f), tuple(r), tuple(u)
+
+
+def parse_scene(text, max_objects=512, max_lights=64):
+    """SceneIO::Load (/root/reference/src/SceneIO.h:108-122) on in-memory text."""
+    objs = np.zeros(max_objects, dtype=L.OBJECT_DTYPE)
+    lts = np.zeros(max_lights, dtype=L.LIGHT_DTYPE)
+    no, nl = ctypes.c_int(0), ctypes.c_int(0)
+    rc = load_library().rt_scene_parse(text.encode("utf-8"), _ptr(objs), max_objects, ctypes.byref(no),
+                                       _ptr(lts), max_lights, ctypes.byref(nl))
+    if rc:
+        raise RtError(rc, "rt_scene_parse")
+    return objs[: no.value].copy(), lts[: nl.value].copy()
+
+
+def strip_local_rows(height, strip_rows, strip_count, strip_index):
+    n = load_library().rt_strip_local_rows(height, strip_rows, strip_count, strip_index)
+    if n < 0:
+        raise RtError(n, "rt_strip_local_rows")
+    return n
+
+
+# ---- the device context ---------------------------------------------------------------------
+class RayTracer:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.rt_create(ctypes.byref(self.ctx), device)
+        if rc:
+            self.ctx = None
+            raise RtError(rc, "rt_create (is a HIP device present?)")
+        self._region = None
+
+    def _check(self, rc, what):
+        if rc:
+            raise RtError(rc, f"{what}: {self.lib.rt_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_scene(self, objects, lights):
+        objects = np.ascontiguousarray(objects)
+        lights = np.ascontiguousarray(lights)
+        assert objects.dtype.itemsize == L.OBJECT_STRIDE and lights.dtype.itemsize == L.LIGHT_STRIDE
+        self._check(self.lib.rt_set_scene(self.ctx, _ptr(objects) if len(objects) else None, len(objects),
+                                          _ptr(lights) if len(lights) else None, len(lights)), "rt_set_scene")
+
+    def set_noise(self, r8):
+        if r8 is None:
+            self._check(self.lib.rt_set_noise(self.ctx, None, 0, 0), "rt_set_noise")
+            return
+        r8 = np.ascontiguousarray(r8, dtype=np.uint8)
+        self._check(self.lib.rt_set_noise(self.ctx, _ptr(r8), r8.shape[1], r8.shape[0]), "rt_set_noise")
+
+    def set_skybox(self, faces):
+        if faces is None:
+            self._check(self.lib.rt_set_skybox(self.ctx, None, 0), "rt_set_skybox")
+            return
+        faces = np.ascontiguousarray(faces, dtype=np.float16)
+        assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 3
+        self._check(self.lib.rt_set_skybox(self.ctx, _ptr(faces), faces.shape[1]), "rt_set_skybox")
+
+    def load(self, scene):
+        """Upload a scenes.Scene (objects, lights, noise, skybox)."""
+        self.set_scene(scene.objects, scene.lights)
+        self.set_noise(scene.noise)
+        self.set_skybox(scene.skybox if scene.use_skybox else None)
+
+    def set_variant(self, v):
+        self._check(self.lib.rt_set_variant(self.ctx, int(v)), "rt_set_variant")
+
+    def render(self, params):
+        self._check(self.lib.rt_render(self.ctx, ctypes.byref(params)), "rt_render")
+        self._region = (params.regionW, params.regionH)
+
+    def render_to(self, params, d_color, d_position, d_normal, stream=None):
+        """Render into caller-owned device memory (raw device pointers as ints)."""
+        self._check(self.lib.rt_render_to(self.ctx, ctypes.byref(params), ctypes.c_void_p(d_color),
+                                          ctypes.c_void_p(d_position), ctypes.c_void_p(d_normal),
+                                          ctypes.c_void_p(stream) if stream else None), "rt_render_to")
+
+    def sync(self):
+        self._check(self.lib.rt_sync(self.ctx), "rt_sync")
+
+    def readback(self):
+        """-> (gColor float32[h,w,4], gPosition float32[h,w,4], gNormal float16[h,w,4]); row 0 = bottom."""
+        w, h = self._region
+        col = np.empty((h, w, 4), dtype=np.float32)
+        pos = np.empty((h, w, 4), dtype=np.float32)
+        nrm = np.empty((h, w, 4), dtype=np.float16)
+        self._check(self.lib.rt_readback(self.ctx, _ptr(col), _ptr(pos), _ptr(nrm)), "rt_readback")
+        return col, pos, nrm
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.rt_last_kernel_ms(self.ctx, ctypes.byref(ms)), "rt_last_kernel_ms")
+        return ms.value
+
+    def count_rays(self, params):
+        n = ctypes.c_uint64()
+        self._check(self.lib.rt_count_rays(self.ctx, ctypes.byref(params), ctypes.byref(n)), "rt_count_rays")
+        return n.value
+
+    def deinterleave(self, d_src, d_dst, width, height, bytes_per_pixel, strip_rows, strip_count,
+                     max_local_rows, stream=None):
+        self._check(self.lib.rt_deinterleave(self.ctx, ctypes.c_void_p(d_src), ctypes.c_void_p(d_dst), width,
+                                             height, bytes_per_pixel, strip_rows, strip_count, max_local_rows,
+                                             ctypes.c_void_p(stream) if stream else None), "rt_deinterleave")

@@ -1,0 +1,155 @@
+"""TEST INFRASTRUCTURE: ctypes binding of oracle/liboracle_rt.so (the CPU restatement) and a
+runner for oracle/_ref/gl_harness (the reference's own GLSL on Mesa llvmpipe).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (opengl_raytracing_amd/) never imports this module.
+"""
+import ctypes
+import json
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+ORACLE_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_rt.so")
+HARNESS = os.path.join(ORACLE_DIR, "_ref", "gl_harness")
+REFERENCE_GLSL = "/root/reference/shader/raytracingCs.glsl"
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            subprocess.run(["make", "-C", ORACLE_DIR, "liboracle_rt.so"], check=True)
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.orc_render.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, ctypes.POINTER(ctypes.c_uint64), ci]
+        lib.orc_render.restype = ci
+        lib.orc_generate_aabb.argtypes = [vp, ci]
+        lib.orc_generate_aabb.restype = None
+        lib.orc_halton.argtypes = [vp, vp, vp, ci]
+        lib.orc_float_to_half_rtz.argtypes = [vp, vp, ci]
+        lib.orc_sample_cube.argtypes = [vp, ci, vp, vp, ci]
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def render(scene, params, nthreads=0):
+    """CPU restatement of one dispatch.  -> (gColor f32[h,w,4], gPosition f32[h,w,4],
+    gNormal f16[h,w,4], rays)."""
+    lib = load()
+    w, h = params.regionW, params.regionH
+    col = np.zeros((h, w, 4), dtype=np.float32)
+    pos = np.zeros((h, w, 4), dtype=np.float32)
+    nrm = np.zeros((h, w, 4), dtype=np.float16)
+    rays = ctypes.c_uint64(0)
+    objs = np.ascontiguousarray(scene.objects)
+    lts = np.ascontiguousarray(scene.lights)
+    noise = np.ascontiguousarray(scene.noise) if scene.noise is not None else None
+    sky = np.ascontiguousarray(scene.skybox) if (scene.skybox is not None and scene.use_skybox) else None
+    rc = lib.orc_render(_ptr(objs), len(objs), _ptr(lts), len(lts), ctypes.byref(params),
+                        _ptr(noise), noise.shape[1] if noise is not None else 0,
+                        noise.shape[0] if noise is not None else 0,
+                        _ptr(sky), sky.shape[1] if sky is not None else 0,
+                        _ptr(col), _ptr(pos), _ptr(nrm), ctypes.byref(rays), nthreads)
+    if rc:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    return col, pos, nrm, rays.value
+
+
+def generate_aabb(objects):
+    load().orc_generate_aabb(_ptr(objects), len(objects))
+    return objects
+
+
+def halton(index, base):
+    index = np.ascontiguousarray(index, dtype=np.int32)
+    base = np.ascontiguousarray(base, dtype=np.int32)
+    out = np.zeros(len(index), dtype=np.float32)
+    load().orc_halton(_ptr(index), _ptr(base), _ptr(out), len(index))
+    return out
+
+
+def float_to_half_rtz(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(x.shape, dtype=np.uint16)
+    load().orc_float_to_half_rtz(_ptr(x), _ptr(out), x.size)
+    return out
+
+
+def sample_cube(sky, dirs):
+    sky = np.ascontiguousarray(sky, dtype=np.float16)
+    dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+    out = np.zeros_like(dirs)
+    load().orc_sample_cube(_ptr(sky), sky.shape[1], _ptr(dirs), _ptr(out), len(dirs))
+    return out
+
+
+# ---- the reference shader itself on Mesa llvmpipe ------------------------------------------
+def harness_available():
+    return os.path.exists(HARNESS) and os.path.exists(REFERENCE_GLSL)
+
+
+def write_job(path, scene, params):
+    """RTJOB1 file for gl_harness (layout: oracle/gl_harness.c JobHeader)."""
+    noise = scene.noise
+    sky = scene.skybox if (scene.skybox is not None and scene.use_skybox) else None
+    hdr = struct.pack(
+        "<8s16i20f", b"RTJOB1\0\0", params.width, params.height, len(scene.objects), len(scene.lights),
+        params.maxRayDepth, params.frameCount, params.useSkybox,
+        noise.shape[1] if noise is not None else 0, noise.shape[0] if noise is not None else 0,
+        sky.shape[1] if sky is not None else 0, 0, 0, 0, 0, 0, 0,
+        *params.camPos, *params.camDir, *params.camUp, *params.camRight,
+        params.fovDeg, params.focalLength, params.maxRayDistance, *params.noiseScale, 0.0, 0.0, 0.0)
+    assert len(hdr) == 152
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(np.ascontiguousarray(scene.objects).tobytes())
+        f.write(np.ascontiguousarray(scene.lights).tobytes())
+        if noise is not None:
+            f.write(np.ascontiguousarray(noise, dtype=np.uint8).tobytes())
+        if sky is not None:
+            f.write(np.ascontiguousarray(sky, dtype=np.float16).tobytes())
+
+
+def run_reference(scene, params, repeat=0, shipped_dispatch=False, threads=None, glsl=REFERENCE_GLSL):
+    """Run the reference's GLSL unmodified (full frame only: GL compute has no dispatch
+    offset).  -> (gColor, gPosition, gNormal-as-f32, info dict)."""
+    if not harness_available():
+        raise RuntimeError("gl_harness or the reference GLSL is not available here")
+    w, h = params.width, params.height
+    with tempfile.TemporaryDirectory(prefix="rtjob_") as d:
+        job = os.path.join(d, "job.bin")
+        write_job(job, scene, params)
+        cmd = [HARNESS, "render", glsl, job, os.path.join(d, "out"), "--repeat", str(repeat)]
+        if shipped_dispatch:
+            cmd.append("--shipped-dispatch")
+        env = dict(os.environ)
+        if threads:
+            env["LP_NUM_THREADS"] = str(threads)
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env)
+        info = json.loads(out.stdout.strip().splitlines()[-1])
+        res = [np.fromfile(os.path.join(d, f"out.{s}.f32"), dtype=np.float32).reshape(h, w, 4)
+               for s in ("color", "pos", "normal")]
+    return res[0], res[1], res[2], info
+
+
+def run_probe(glsl_text, in_array, out_dtype, out_count, groups):
+    """Micro-kernel mode: SSBO 0 = in_array bytes, SSBO 1 = out_count items of out_dtype."""
+    with tempfile.TemporaryDirectory(prefix="rtprobe_") as d:
+        g, i, o = (os.path.join(d, n) for n in ("p.glsl", "in.bin", "out.bin"))
+        with open(g, "w") as f:
+            f.write(glsl_text)
+        np.ascontiguousarray(in_array).tofile(i)
+        nbytes = int(np.dtype(out_dtype).itemsize * out_count)
+        subprocess.run([HARNESS, "probe", g, i, o, str(nbytes), str(groups)], check=True, capture_output=True)
+        return np.fromfile(o, dtype=out_dtype)

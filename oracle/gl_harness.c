@@ -1,0 +1,471 @@
+/*
+ * gl_harness.c -- TEST INFRASTRUCTURE (oracle side), never linked into the product.
+ *
+ * Runs a GLSL 4.30 compute shader -- in practice the reference's own
+ * shader/raytracingCs.glsl, passed BY PATH at run time and never copied into
+ * this repository -- on Mesa llvmpipe through the raw DRI "swrast" loader
+ * interface (no X server, no EGL, no GLFW/GLEW needed).  It reproduces the ~20
+ * GL calls of the reference dispatch site
+ *   /root/reference/src/ForwardShadingPipeline.cpp:155-182  (uniforms + dispatch)
+ *   /root/reference/src/ForwardShadingPipeline.cpp:57-65,115-126 (3 output images)
+ *   /root/reference/src/SSBO.h:16-23, LightSSBO.h:16-25     (SSBO upload, bindings 0/1)
+ * with two deliberate, documented differences:
+ *   - exact dispatch ceil(W/32) x ceil(H/32) by default ("--shipped-dispatch"
+ *     reproduces the reference's 4x over-dispatch (W+15)/16 for timing only);
+ *   - the noise sampler gets its own texture unit (1); "no noise" binds a 1x1
+ *     zero texel, which is bit-identical to what the shipped binary samples.
+ *
+ * Modes
+ *   gl_harness render <shader.glsl> <job.bin> <out_prefix> [--repeat N] [--shipped-dispatch]
+ *        job.bin = "RTJOB1" file written by tests/golden/make_golden.py (layout below).
+ *        Writes <out_prefix>.color.f32 / .pos.f32 / .normal.f32  (W*H*4 float each,
+ *        row 0 = bottom row, GL origin) and prints one JSON line with timings.
+ *   gl_harness probe  <probe.glsl> <in.bin> <out.bin> <out_bytes> <groups_x>
+ *        micro-kernel mode: SSBO binding 0 = in.bin, SSBO binding 1 = out (zeroed),
+ *        glDispatchCompute(groups_x,1,1).  Used to pin llvmpipe's lowering of
+ *        individual GLSL built-ins.
+ *
+ * Build: gcc -O2 -o _ref/gl_harness gl_harness.c -ldl -lm   (see oracle/Makefile)
+ * Skips (exit code 77) when Mesa's swrast_dri.so / libglapi.so.0 are absent.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define GL_GLEXT_PROTOTYPES 0
+#include <GL/gl.h>
+#include <GL/glext.h>
+#include <GL/internal/dri_interface.h>
+
+#define EXIT_SKIP 77
+
+/* ------------------------------------------------------------------ job file */
+#pragma pack(push, 1)
+typedef struct {
+    char magic[8]; /* "RTJOB1\0\0" */
+    int32_t width, height;
+    int32_t nObj, nLt;
+    int32_t maxRayDepth;
+    int32_t frameCount;
+    int32_t useSkybox;
+    int32_t noiseW, noiseH; /* 0 => no noise texture (shipped behaviour) */
+    int32_t skySize;        /* 0 => no cubemap; faces are skySize^2 RGB fp16 */
+    int32_t reserved[6];
+    float camPos[3], camDir[3], camUp[3], camRight[3];
+    float fovDeg, focalLength, maxRayDistance;
+    float noiseScale[2];
+    float reservedf[3];
+} JobHeader; /* 8 + 16*4 + 20*4 = 152 bytes */
+#pragma pack(pop)
+
+/* ------------------------------------------------------------------ GL entry points */
+static void *(*gpa)(const char *);
+#define GLF(ret, name, ...) static ret (*p_##name)(__VA_ARGS__)
+GLF(GLenum, glGetError, void);
+GLF(const GLubyte *, glGetString, GLenum);
+GLF(GLuint, glCreateShader, GLenum);
+GLF(void, glShaderSource, GLuint, GLsizei, const GLchar *const *, const GLint *);
+GLF(void, glCompileShader, GLuint);
+GLF(void, glGetShaderiv, GLuint, GLenum, GLint *);
+GLF(void, glGetShaderInfoLog, GLuint, GLsizei, GLsizei *, GLchar *);
+GLF(GLuint, glCreateProgram, void);
+GLF(void, glAttachShader, GLuint, GLuint);
+GLF(void, glLinkProgram, GLuint);
+GLF(void, glGetProgramiv, GLuint, GLenum, GLint *);
+GLF(void, glGetProgramInfoLog, GLuint, GLsizei, GLsizei *, GLchar *);
+GLF(void, glUseProgram, GLuint);
+GLF(GLint, glGetUniformLocation, GLuint, const GLchar *);
+GLF(void, glUniform1i, GLint, GLint);
+GLF(void, glUniform1f, GLint, GLfloat);
+GLF(void, glUniform2f, GLint, GLfloat, GLfloat);
+GLF(void, glUniform3f, GLint, GLfloat, GLfloat, GLfloat);
+GLF(void, glGenTextures, GLsizei, GLuint *);
+GLF(void, glBindTexture, GLenum, GLuint);
+GLF(void, glActiveTexture, GLenum);
+GLF(void, glTexImage2D, GLenum, GLint, GLint, GLsizei, GLsizei, GLint, GLenum, GLenum, const void *);
+GLF(void, glTexParameteri, GLenum, GLenum, GLint);
+GLF(void, glPixelStorei, GLenum, GLint);
+GLF(void, glBindImageTexture, GLuint, GLuint, GLint, GLboolean, GLint, GLenum, GLenum);
+GLF(void, glGenBuffers, GLsizei, GLuint *);
+GLF(void, glBindBuffer, GLenum, GLuint);
+GLF(void, glBufferData, GLenum, GLsizeiptr, const void *, GLenum);
+GLF(void, glBindBufferBase, GLenum, GLuint, GLuint);
+GLF(void, glGetBufferSubData, GLenum, GLintptr, GLsizeiptr, void *);
+GLF(void, glDispatchCompute, GLuint, GLuint, GLuint);
+GLF(void, glMemoryBarrier, GLbitfield);
+GLF(void, glFinish, void);
+GLF(void, glGetTexImage, GLenum, GLint, GLenum, GLenum, void *);
+
+#define LOAD(name)                                             \
+    do {                                                       \
+        p_##name = (void *)gpa(#name);                         \
+        if (!p_##name) {                                       \
+            fprintf(stderr, "missing GL entry %s\n", #name);   \
+            exit(2);                                           \
+        }                                                      \
+    } while (0)
+
+static void load_gl(void) {
+    LOAD(glGetError); LOAD(glGetString); LOAD(glCreateShader); LOAD(glShaderSource);
+    LOAD(glCompileShader); LOAD(glGetShaderiv); LOAD(glGetShaderInfoLog);
+    LOAD(glCreateProgram); LOAD(glAttachShader); LOAD(glLinkProgram);
+    LOAD(glGetProgramiv); LOAD(glGetProgramInfoLog); LOAD(glUseProgram);
+    LOAD(glGetUniformLocation); LOAD(glUniform1i); LOAD(glUniform1f);
+    LOAD(glUniform2f); LOAD(glUniform3f); LOAD(glGenTextures); LOAD(glBindTexture);
+    LOAD(glActiveTexture); LOAD(glTexImage2D); LOAD(glTexParameteri); LOAD(glPixelStorei);
+    LOAD(glBindImageTexture); LOAD(glGenBuffers); LOAD(glBindBuffer); LOAD(glBufferData);
+    LOAD(glBindBufferBase); LOAD(glGetBufferSubData); LOAD(glDispatchCompute);
+    LOAD(glMemoryBarrier); LOAD(glFinish); LOAD(glGetTexImage);
+}
+
+static void gl_check(const char *where) {
+    GLenum e = p_glGetError();
+    if (e != GL_NO_ERROR) {
+        fprintf(stderr, "GL error 0x%x at %s\n", e, where);
+        exit(3);
+    }
+}
+
+/* ------------------------------------------------------------------ DRI swrast bootstrap */
+static void cb_getDrawableInfo(__DRIdrawable *d, int *x, int *y, int *w, int *h, void *p) {
+    (void)d; (void)p; *x = 0; *y = 0; *w = 16; *h = 16;
+}
+static void cb_putImage(__DRIdrawable *d, int op, int x, int y, int w, int h, char *data, void *p) {
+    (void)d; (void)op; (void)x; (void)y; (void)w; (void)h; (void)data; (void)p;
+}
+static void cb_getImage(__DRIdrawable *d, int x, int y, int w, int h, char *data, void *p) {
+    (void)d; (void)x; (void)y; (void)p; memset(data, 0, (size_t)w * h * 4);
+}
+static void cb_putImage2(__DRIdrawable *d, int op, int x, int y, int w, int h, int stride, char *data, void *p) {
+    (void)d; (void)op; (void)x; (void)y; (void)w; (void)h; (void)stride; (void)data; (void)p;
+}
+static void cb_getImage2(__DRIdrawable *d, int x, int y, int w, int h, int stride, char *data, void *p) {
+    (void)d; (void)x; (void)y; (void)w; (void)p; memset(data, 0, (size_t)stride * h);
+}
+
+static int bootstrap_gl(void) {
+    void *glapi = dlopen("libglapi.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!glapi) return -1;
+    gpa = (void *(*)(const char *))dlsym(glapi, "_glapi_get_proc_address");
+    if (!gpa) return -1;
+    const char *drvpath = getenv("RT_SWRAST_DRI");
+    if (!drvpath) drvpath = "/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so";
+    void *drv = dlopen(drvpath, RTLD_NOW | RTLD_GLOBAL);
+    if (!drv) return -1;
+    const __DRIextension **(*getExts)(void) =
+        (const __DRIextension **(*)(void))dlsym(drv, "__driDriverGetExtensions_swrast");
+    if (!getExts) return -1;
+    const __DRIextension **exts = getExts();
+    const __DRIcoreExtension *core = NULL;
+    const __DRIswrastExtension *swr = NULL;
+    for (int i = 0; exts[i]; i++) {
+        if (!strcmp(exts[i]->name, __DRI_CORE)) core = (const __DRIcoreExtension *)exts[i];
+        if (!strcmp(exts[i]->name, __DRI_SWRAST)) swr = (const __DRIswrastExtension *)exts[i];
+    }
+    if (!core || !swr || swr->base.version < 4) return -1;
+
+    static __DRIswrastLoaderExtension loader;
+    loader.base.name = __DRI_SWRAST_LOADER;
+    loader.base.version = 3;
+    loader.getDrawableInfo = cb_getDrawableInfo;
+    loader.putImage = cb_putImage;
+    loader.getImage = cb_getImage;
+    loader.putImage2 = cb_putImage2;
+    loader.getImage2 = cb_getImage2;
+    static const __DRIextension *lexts[2];
+    lexts[0] = &loader.base;
+    lexts[1] = NULL;
+
+    const __DRIconfig **cfgs = NULL;
+    __DRIscreen *scr = swr->createNewScreen2(0, lexts, exts, &cfgs, NULL);
+    if (!scr || !cfgs || !cfgs[0]) return -1;
+    uint32_t at[] = {__DRI_CTX_ATTRIB_MAJOR_VERSION, 4, __DRI_CTX_ATTRIB_MINOR_VERSION, 3};
+    unsigned err = 0;
+    __DRIcontext *ctx = swr->createContextAttribs(scr, __DRI_API_OPENGL_CORE, cfgs[0], NULL, 2, at, &err, NULL);
+    if (!ctx) return -1;
+    __DRIdrawable *dr = swr->createNewDrawable(scr, cfgs[0], NULL);
+    if (!dr) return -1;
+    if (!core->bindContext(ctx, dr, dr)) return -1;
+    load_gl();
+    return 0;
+}
+
+/* ------------------------------------------------------------------ helpers */
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static char *read_file(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); return NULL; }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *buf = malloc((size_t)n + 1);
+    if (fread(buf, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(buf); return NULL; }
+    buf[n] = 0;
+    fclose(f);
+    if (len) *len = (size_t)n;
+    return buf;
+}
+
+static int write_file(const char *path, const void *data, size_t n) {
+    FILE *f = fopen(path, "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", path); return -1; }
+    size_t w = fwrite(data, 1, n, f);
+    fclose(f);
+    return w == n ? 0 : -1;
+}
+
+/* Replace the integer after "#define MAX_RAY_DEPTH" (the single token edit the
+ * configs need).  Returns a fresh buffer. */
+static char *patch_depth(const char *src, int depth) {
+    const char *key = "#define MAX_RAY_DEPTH";
+    const char *p = strstr(src, key);
+    if (!p) { fprintf(stderr, "shader has no MAX_RAY_DEPTH define\n"); exit(2); }
+    const char *q = p + strlen(key);
+    while (*q == ' ' || *q == '\t') q++;
+    const char *e = q;
+    while (*e >= '0' && *e <= '9') e++;
+    size_t n = strlen(src);
+    char *out = malloc(n + 32);
+    size_t pre = (size_t)(q - src);
+    memcpy(out, src, pre);
+    int w = sprintf(out + pre, "%d", depth);
+    strcpy(out + pre + w, e);
+    return out;
+}
+
+static GLuint build_program(const char *src, double *compile_s) {
+    double t0 = now_s();
+    GLuint sh = p_glCreateShader(GL_COMPUTE_SHADER);
+    p_glShaderSource(sh, 1, &src, NULL);
+    p_glCompileShader(sh);
+    GLint ok = 0;
+    p_glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+    if (!ok) {
+        char log[8192];
+        p_glGetShaderInfoLog(sh, sizeof log, NULL, log);
+        fprintf(stderr, "compile failed:\n%s\n", log);
+        exit(4);
+    }
+    GLuint prog = p_glCreateProgram();
+    p_glAttachShader(prog, sh);
+    p_glLinkProgram(prog);
+    p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (!ok) {
+        char log[8192];
+        p_glGetProgramInfoLog(prog, sizeof log, NULL, log);
+        fprintf(stderr, "link failed:\n%s\n", log);
+        exit(4);
+    }
+    if (compile_s) *compile_s = now_s() - t0;
+    return prog;
+}
+
+static GLuint make_image(GLuint unit, GLenum ifmt, int w, int h) {
+    GLuint t;
+    p_glGenTextures(1, &t);
+    p_glBindTexture(GL_TEXTURE_2D, t);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, (GLint)ifmt, w, h, 0, GL_RGBA, GL_FLOAT, NULL);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    p_glBindImageTexture(unit, t, 0, GL_FALSE, 0, GL_WRITE_ONLY, ifmt);
+    return t;
+}
+
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* ------------------------------------------------------------------ render mode */
+static int mode_render(int argc, char **argv) {
+    if (argc < 5) { fprintf(stderr, "usage: render <glsl> <job.bin> <out_prefix> [--repeat N] [--shipped-dispatch]\n"); return 2; }
+    const char *glsl_path = argv[2], *job_path = argv[3], *prefix = argv[4];
+    int repeat = 1, shipped = 0;
+    for (int i = 5; i < argc; i++) {
+        if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--shipped-dispatch")) shipped = 1;
+    }
+    char *src0 = read_file(glsl_path, NULL);
+    if (!src0) return EXIT_SKIP; /* no reference shader here (e.g. on the GPU box) */
+    size_t joblen = 0;
+    char *job = read_file(job_path, &joblen);
+    if (!job || joblen < sizeof(JobHeader)) return 2;
+    JobHeader hd;
+    memcpy(&hd, job, sizeof hd);
+    if (memcmp(hd.magic, "RTJOB1", 6)) { fprintf(stderr, "bad job magic\n"); return 2; }
+    const char *p = job + sizeof hd;
+    const void *objBytes = p; p += (size_t)hd.nObj * 176;
+    const void *ltBytes = p;  p += (size_t)hd.nLt * 96;
+    const void *noise = p;    p += (size_t)hd.noiseW * hd.noiseH;
+    const void *sky = p;      p += (size_t)6 * hd.skySize * hd.skySize * 3 * 2;
+    if ((size_t)(p - job) > joblen) { fprintf(stderr, "job truncated\n"); return 2; }
+
+    if (bootstrap_gl()) { fprintf(stderr, "Mesa swrast unavailable\n"); return EXIT_SKIP; }
+    char *src = patch_depth(src0, hd.maxRayDepth);
+    double compile_s = 0;
+    GLuint prog = build_program(src, &compile_s);
+    p_glUseProgram(prog);
+
+    const int W = hd.width, H = hd.height;
+    GLuint tColor = make_image(0, GL_RGBA32F, W, H);
+    GLuint tPos = make_image(1, GL_RGBA32F, W, H);
+    GLuint tNrm = make_image(2, GL_RGBA16F, W, H);
+    gl_check("images");
+
+    GLuint bufs[2];
+    p_glGenBuffers(2, bufs);
+    p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[0]);
+    p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)hd.nObj * 176 + (hd.nObj ? 0 : 176), hd.nObj ? objBytes : NULL, GL_DYNAMIC_DRAW);
+    p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 0, bufs[0]);
+    p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[1]);
+    p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)hd.nLt * 96 + (hd.nLt ? 0 : 96), hd.nLt ? ltBytes : NULL, GL_DYNAMIC_DRAW);
+    p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, bufs[1]);
+    gl_check("ssbo");
+
+    /* noise texture on unit 1 (R8, NEAREST, REPEAT) */
+    GLuint tNoise;
+    p_glGenTextures(1, &tNoise);
+    p_glActiveTexture(GL_TEXTURE1);
+    p_glBindTexture(GL_TEXTURE_2D, tNoise);
+    p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+    if (hd.noiseW > 0) {
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_R8, hd.noiseW, hd.noiseH, 0, GL_RED, GL_UNSIGNED_BYTE, noise);
+    } else {
+        const unsigned char z = 0;
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_R8, 1, 1, 0, GL_RED, GL_UNSIGNED_BYTE, &z);
+    }
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_REPEAT);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_REPEAT);
+    gl_check("noise");
+
+    /* cubemap on unit 0: RGB16F, LINEAR, CLAMP_TO_EDGE, not seamless
+     * (/root/reference/src/TextureLoader.cpp:140-147) */
+    if (hd.skySize > 0) {
+        GLuint tSky;
+        p_glGenTextures(1, &tSky);
+        p_glActiveTexture(GL_TEXTURE0);
+        p_glBindTexture(GL_TEXTURE_CUBE_MAP, tSky);
+        size_t face = (size_t)hd.skySize * hd.skySize * 3 * 2;
+        for (int f = 0; f < 6; f++)
+            p_glTexImage2D(GL_TEXTURE_CUBE_MAP_POSITIVE_X + f, 0, GL_RGB16F, hd.skySize, hd.skySize, 0,
+                           GL_RGB, GL_HALF_FLOAT, (const char *)sky + f * face);
+        p_glTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+        p_glTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+        p_glTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_WRAP_R, GL_CLAMP_TO_EDGE);
+        p_glTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+        p_glTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+        gl_check("skybox");
+    }
+
+#define U(name) p_glGetUniformLocation(prog, name)
+    p_glUniform1i(U("numObjects"), hd.nObj);
+    p_glUniform1i(U("numLights"), hd.nLt);
+    p_glUniform3f(U("cameraPos"), hd.camPos[0], hd.camPos[1], hd.camPos[2]);
+    p_glUniform3f(U("cameraDir"), hd.camDir[0], hd.camDir[1], hd.camDir[2]);
+    p_glUniform3f(U("cameraUp"), hd.camUp[0], hd.camUp[1], hd.camUp[2]);
+    p_glUniform3f(U("cameraRight"), hd.camRight[0], hd.camRight[1], hd.camRight[2]);
+    p_glUniform1f(U("fov"), hd.fovDeg);
+    p_glUniform1f(U("focalLength"), hd.focalLength);
+    p_glUniform1f(U("maxRayDistance"), hd.maxRayDistance);
+    p_glUniform1i(U("frameCount"), hd.frameCount);
+    p_glUniform2f(U("noiseScale"), hd.noiseScale[0], hd.noiseScale[1]);
+    p_glUniform1i(U("useSkybox"), hd.useSkybox);
+    p_glUniform1i(U("skybox"), 0);
+    p_glUniform1i(U("blueNoiseTex"), 1);
+    gl_check("uniforms");
+
+    GLuint gx = shipped ? (GLuint)((W + 15) / 16) : (GLuint)((W + 31) / 32);
+    GLuint gy = shipped ? (GLuint)((H + 15) / 16) : (GLuint)((H + 31) / 32);
+
+    /* first dispatch includes the llvmpipe JIT; timed dispatches follow */
+    double t0 = now_s();
+    p_glDispatchCompute(gx, gy, 1);
+    p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
+    p_glFinish();
+    double first_s = now_s() - t0;
+    gl_check("dispatch");
+
+    double *times = calloc((size_t)(repeat > 0 ? repeat : 1), sizeof(double));
+    for (int r = 0; r < repeat; r++) {
+        t0 = now_s();
+        p_glDispatchCompute(gx, gy, 1);
+        p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
+        p_glFinish();
+        times[r] = now_s() - t0;
+    }
+    double median = first_s;
+    if (repeat > 0) {
+        qsort(times, (size_t)repeat, sizeof(double), cmp_double);
+        median = times[repeat / 2];
+    }
+
+    size_t npx = (size_t)W * H;
+    float *buf = malloc(npx * 4 * sizeof(float));
+    char path[4096];
+    GLuint texs[3] = {tColor, tPos, tNrm};
+    const char *suffix[3] = {"color", "pos", "normal"};
+    p_glActiveTexture(GL_TEXTURE2);
+    for (int i = 0; i < 3; i++) {
+        p_glBindTexture(GL_TEXTURE_2D, texs[i]);
+        p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, buf);
+        gl_check("readback");
+        snprintf(path, sizeof path, "%s.%s.f32", prefix, suffix[i]);
+        if (write_file(path, buf, npx * 4 * sizeof(float))) return 5;
+    }
+    printf("{\"renderer\": \"%s\", \"version\": \"%s\", \"width\": %d, \"height\": %d, "
+           "\"groups\": [%u, %u], \"shipped_dispatch\": %d, \"compile_s\": %.6f, "
+           "\"first_dispatch_s\": %.6f, \"median_dispatch_s\": %.6f, \"repeat\": %d}\n",
+           (const char *)p_glGetString(GL_RENDERER), (const char *)p_glGetString(GL_VERSION), W, H, gx, gy,
+           shipped, compile_s, first_s, median, repeat);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ probe mode */
+static int mode_probe(int argc, char **argv) {
+    if (argc < 7) { fprintf(stderr, "usage: probe <glsl> <in.bin> <out.bin> <out_bytes> <groups_x>\n"); return 2; }
+    char *src = read_file(argv[2], NULL);
+    size_t inlen = 0;
+    char *in = read_file(argv[3], &inlen);
+    if (!src || !in) return 2;
+    size_t outlen = (size_t)atol(argv[5]);
+    GLuint groups = (GLuint)atoi(argv[6]);
+    if (bootstrap_gl()) { fprintf(stderr, "Mesa swrast unavailable\n"); return EXIT_SKIP; }
+    GLuint prog = build_program(src, NULL);
+    p_glUseProgram(prog);
+    GLuint bufs[2];
+    p_glGenBuffers(2, bufs);
+    p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[0]);
+    p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)inlen, in, GL_DYNAMIC_DRAW);
+    p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 0, bufs[0]);
+    void *zero = calloc(1, outlen);
+    p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[1]);
+    p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)outlen, zero, GL_DYNAMIC_DRAW);
+    p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, bufs[1]);
+    p_glDispatchCompute(groups, 1, 1);
+    p_glMemoryBarrier(GL_ALL_BARRIER_BITS);
+    p_glFinish();
+    gl_check("probe dispatch");
+    p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[1]);
+    p_glGetBufferSubData(GL_SHADER_STORAGE_BUFFER, 0, (GLsizeiptr)outlen, zero);
+    gl_check("probe readback");
+    return write_file(argv[4], zero, outlen) ? 5 : 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: gl_harness render|probe ...\n"); return 2; }
+    if (!strcmp(argv[1], "render")) return mode_render(argc, argv);
+    if (!strcmp(argv[1], "probe")) return mode_probe(argc, argv);
+    fprintf(stderr, "unknown mode %s\n", argv[1]);
+    return 2;
+}
