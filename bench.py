@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its named workload, on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame: one pass of the ray-tracing hot path over the workload's pixels, with
+the scene, textures and output surfaces already resident in HBM (the reference re-uploads its
+<= 4 KB of SSBOs per frame; the PCIe-inclusive figure is in DESIGN.md, never `value`).
+
+Workload (N = 1 and N > 1 alike): BASELINE.json configs[1] -- 1920x1080, 16 spheres + 2
+planes, 3 lights (point / directional / area), MAX_RAY_DEPTH 4, PCF x4 shadows, synthetic
+scene of SURVEY.md 8(d).  N > 1 splits that one frame into interleaved 16-row strips, one
+process per GPU, and assembles the image on rank 0 with one RCCL gather per surface + a copy
+kernel -- all inside the timed step ("scaling": "strong").
+
+Rank 0 prints ONE JSON line: metric Mray/s (rays = intersectObjects calls, counted exactly by
+an instrumented launch before the timed region), ms_per_step, `roofline` (algorithmic bytes
+of SURVEY.md 8(d) / live HIP-event kernel time) and, at N = 1, `cpu_baseline` (the oracle --
+the scalar CPU restatement -- timed on this box's host cores on whole frames of the same
+workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes(rays, n_obj, n_lt, n_px, noise_bound, sky_taps):
+    """the scene-record stream the reference shader reads per ray
+    (`Object obj = objects[i]`, raytracingCs.glsl:159-160) + compulsory outputs/inputs."""
+    return rays * n_obj * 176 + n_px * 40 + (n_px if noise_bound else 0) + sky_taps * 24 + n_obj * 176 + n_lt * 96
+
+
+def host_threads():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index 1..5 (default 2 = the metric's)")
+    ap.add_argument("--strip-rows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from opengl_raytracing_amd import dist as D
+    from opengl_raytracing_amd import host, scenes
+
+    sc = scenes.make_scene(args.config, host.generate_aabb)
+    W, H = sc.width, sc.height
+    base = sc.params()
+    rt = host.RayTracer(local_rank)
+    rt.load(sc)
+    rt.set_variant(args.variant)
+
+    strip_rows = args.strip_rows or D.default_strip_rows(H, world)
+    plan = D.StripPlan(W, H, strip_rows, world) if world > 1 else D.StripPlan(W, H, H, 1)
+    p = plan.params(base, rank) if world > 1 else base
+    rows = plan.max_local_rows if world > 1 else H
+    dev = torch.device("cuda", local_rank)
+    s_col = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
+    s_pos = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
+    s_nrm = torch.empty((rows, W, 4), dtype=torch.float16, device=dev)
+    full = None
+    if world > 1 and rank == 0:
+        full = [torch.empty((H, W, 4), dtype=t.dtype, device=dev) for t in (s_col, s_pos, s_nrm)]
+    # a dedicated (non-null) torch stream: the render kernel is launched on it through the ABI,
+    # RCCL orders against it, and torch.cuda.Event timings see exactly these launches
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+
+    def step():
+        rt.render_to(p, s_col.data_ptr(), s_pos.data_ptr(), s_nrm.data_ptr(), stream=stream.cuda_stream)
+        if world > 1:
+            g = D.gather_strips([s_col, s_pos, s_nrm], plan, rank)
+            if rank == 0:
+                for src, dst in zip(g, full):
+                    D.deinterleave_hip(rt, src, plan, out=dst, stream=stream.cuda_stream)
+
+    # exact ray count of this rank's pixels (instrumented launch, outside the timed region)
+    my_rays = rt.count_rays(p)
+    rays_t = torch.tensor([my_rays], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays_t)
+    frame_rays = int(rays_t.item())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # dominant kernel's average launch duration: HIP events on the launch stream, kernel only
+    # (a second pass of K back-to-back launches so that at N>1 the gather is not inside it)
+    kev0, kev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kev0.record(stream)
+    for _ in range(args.steps):
+        rt.render_to(p, s_col.data_ptr(), s_pos.data_ptr(), s_nrm.data_ptr(), stream=stream.cuda_stream)
+    kev1.record(stream)
+    torch.cuda.synchronize()
+    kernel_ms = kev0.elapsed_time(kev1) / args.steps
+    step_ms_dev = ev0.elapsed_time(ev1) / args.steps
+
+    if rank == 0:
+        n_px = W * H
+        ms_per_step = elapsed / args.steps * 1e3
+        value = frame_rays * args.steps / elapsed / 1e6
+        my_px = plan.local_rows(rank) * W if world > 1 else n_px
+        b_alg = algorithmic_bytes(my_rays, len(sc.objects), len(sc.lights), my_px, sc.noise is not None, 0)
+        achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get(f"c{args.config}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        compulsory = (my_px * 40 + len(sc.objects) * 176 + len(sc.lights) * 96) / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mray/s", "value": round(value, 1), "unit": "Mray/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C{args.config}: {W}x{H}, {len(sc.objects)} objects "
+                                   f"({int((sc.objects['type'] == 0).sum())} spheres + {int((sc.objects['type'] == 1).sum())} planes), "
+                                   f"{len(sc.lights)} lights, depth {sc.max_ray_depth}, "
+                                   f"{'PCSS' if int(sc.lights['shadowType'][0]) == 2 else 'PCF x4'} shadows",
+                       "width": W, "height": H, "max_ray_depth": sc.max_ray_depth,
+                       "parallelism": f"{world} x interleaved {strip_rows}-row strips + RCCL gather" if world > 1 else "1 GPU",
+                       "rays_per_frame": frame_rays, "rays_per_pixel": round(frame_rays / n_px, 3)},
+            "mpx_per_s": round(n_px * args.steps / elapsed / 1e6, 1),
+            "kernel_ms": round(kernel_ms, 4), "step_ms_device": round(step_ms_dev, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 3), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "note": "algorithmic bytes = rays*nObj*176 + px*40 + scene (SURVEY.md 8(d)); the stream is "
+                                 "served from LDS, so achieved may exceed the HBM peak -- it is not physical bandwidth",
+                         "compulsory_only_GBps": round(compulsory, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import binding as O   # checker / reported baseline only
+            O.load()
+            threads = host_threads()
+            t_cpu, n_frames = 0.0, 0
+            O.render(sc, sc.params(width=W // 8, height=H // 8))   # warm
+            while t_cpu < 10.0 and n_frames < 8:
+                c0 = time.perf_counter()
+                _, _, _, r_cpu = O.render(sc, base, nthreads=threads)
+                t_cpu += time.perf_counter() - c0
+                n_frames += 1
+            out["cpu_baseline"] = {"value": round(r_cpu * n_frames / t_cpu / 1e6, 2), "unit": "Mray/s", "cores": threads,
+                                   "kind": "port",
+                                   "sample": f"{n_frames} whole frame(s) of the same workload ({r_cpu} rays each) in "
+                                             f"{t_cpu:.1f} s; scalar fp32 C restatement (oracle/rt_oracle.c), OpenMP over rows",
+                                   "ms_per_frame": round(t_cpu / n_frames * 1e3, 1)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    rt.close()
+
+
+if __name__ == "__main__":
+    main()

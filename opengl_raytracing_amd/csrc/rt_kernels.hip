@@ -592,7 +592,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void rt_render_kernel(const RtFrame 
         int idx = trace_closest<COUNT>(sc, f.nObj, ray, f.p.maxRayDistance, t, rays);
         if (idx < 0) {
             if (f.p.useSkybox && dsc.sky) finalColor = finalColor + throughput * sample_cube(dsc.sky, f.skySize, ray.d);
-            else finalColor = finalColor + throughput * V3(0.0f, 0.0f, 0.0f);
+            // else `finalColor += throughput * vec3(0.0)` (:532): x*0.0 folds to 0.0 on the reference's
+            // GL, so a NaN/inf throughput does not poison the colour on a miss (nan fixture).
             break;
         }
         // hit normal (:187-191): sphere = normalize(hit - centre); plane = raw normal
@@ -653,15 +654,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) void rt_render_kernel(const RtFrame 
 // =========================================================================================
 // Rank-0 reassembly of gathered interleaved strips (multi-GPU): pure copy kernel, 16 B/lane.
 // =========================================================================================
-__global__ void rt_deinterleave_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int rowU4,
+template <typename U>
+__global__ void rt_deinterleave_kernel(const U *__restrict__ src, U *__restrict__ dst, int rowUnits,
                                        int height, int stripRows, int stripCount, int maxLocalRows) {
-    const size_t total = (size_t)rowU4 * height;
+    const size_t total = (size_t)rowUnits * height;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
-        int y = (int)(k / rowU4), c = (int)(k % rowU4);
+        int y = (int)(k / rowUnits), c = (int)(k % rowUnits);
         int strip = y / stripRows;
         int rank = strip % stripCount, localStrip = strip / stripCount;
         int ly = localStrip * stripRows + y % stripRows;
-        dst[k] = src[((size_t)rank * maxLocalRows + ly) * rowU4 + c];
+        dst[k] = src[((size_t)rank * maxLocalRows + ly) * rowUnits + c];
     }
 }
 
@@ -690,13 +692,22 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
                                   int stripRows, int stripCount, int maxLocalRows, hipStream_t s) {
     size_t rowBytes = (size_t)width * bytesPerPixel;
-    if (rowBytes % 16 != 0) return hipErrorInvalidValue;
-    int rowU4 = (int)(rowBytes / 16);
-    size_t total = (size_t)rowU4 * height;
+    // widest unit that divides a row: 16 B/lane for the rgba32f surfaces and even-width rgba16f
+    int unit = (rowBytes % 16 == 0) ? 16 : (rowBytes % 8 == 0) ? 8 : (rowBytes % 4 == 0) ? 4 : 0;
+    if (!unit) return hipErrorInvalidValue;
+    int rowUnits = (int)(rowBytes / unit);
+    size_t total = (size_t)rowUnits * height;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(rt_deinterleave_kernel, dim3(blocks), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst, rowU4,
-                       height, stripRows, stripCount, maxLocalRows);
+    if (unit == 16)
+        hipLaunchKernelGGL(rt_deinterleave_kernel<uint4>, dim3(blocks), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst,
+                           rowUnits, height, stripRows, stripCount, maxLocalRows);
+    else if (unit == 8)
+        hipLaunchKernelGGL(rt_deinterleave_kernel<uint2>, dim3(blocks), dim3(256), 0, s, (const uint2 *)src, (uint2 *)dst,
+                           rowUnits, height, stripRows, stripCount, maxLocalRows);
+    else
+        hipLaunchKernelGGL(rt_deinterleave_kernel<unsigned>, dim3(blocks), dim3(256), 0, s, (const unsigned *)src,
+                           (unsigned *)dst, rowUnits, height, stripRows, stripCount, maxLocalRows);
     return hipGetLastError();
 }

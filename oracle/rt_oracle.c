@@ -555,8 +555,9 @@ static void shade_pixel(Ctx *c, float *color, float *pos, uint16_t *nrm) {
         if (!intersectObjects(c, &ray, &mat, &N, &t)) {
             if (p->useSkybox && c->sky)
                 finalColor = add3(finalColor, mul3(throughput, sample_cube(c->sky, c->skySize, ray.direction)));
-            else
-                finalColor = add3(finalColor, mul3(throughput, V3(0, 0, 0)));
+            /* else: `finalColor += throughput * vec3(0.0)` (:532).  Mesa folds x*0.0 to 0.0
+             * (inexact algebra), so a NaN/inf throughput does NOT poison the colour on a miss:
+             * pinned by the nan fixture (tests/golden/nan.npz). */
             break;
         }
         P = add3(ray.origin, scale3(ray.direction, t));

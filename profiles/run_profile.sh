@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py's dominant kernel on the GPU box.
+#   usage (from the repo root, on the box):  bash profiles/run_profile.sh <tag> [bench args...]
+# Writes raw output under gpurun_out/prof_<tag>/ (scratch); summarize.py turns it into the
+# committed profiles/<tag>_*.csv/json.  Kernel-trace/stats and each PMC group are SEPARATE
+# runs (gpurun refuses --pmc together with trace domains other than kernel-trace/stats).
+set -o pipefail
+TAG=${1:-r01}; shift
+ARGS=${@:---steps 30 --warmup 5 --no-cpu-baseline}
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_${TAG}
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pmc group failed: $grp"; tail -5 $OUT/pmc_$name.log; }
+done
+python3 profiles/summarize.py $OUT profiles/${TAG}

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 csv output (run_profile.sh) into small committed summaries:
+<prefix>_kernel_stats.csv (per-kernel count / avg / total from the kernel trace) and
+<prefix>_pmc.json (per-kernel mean of every counter collected, per dispatch)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main(src, prefix):
+    stats = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row.get("Kernel_Name", "?")
+            dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+            s = stats[name]
+            s[0] += 1; s[1] += dur; s[2] = min(s[2], dur); s[3] = max(s[3], dur)
+            s.append(None) if False else None
+            stats[name + "|meta"] = [row.get("VGPR_Count", ""), row.get("SGPR_Count", ""), row.get("LDS_Block_Size", ""),
+                                     row.get("Workgroup_Size", row.get("Workgroup_Size_X", "")), row.get("Grid_Size", row.get("Grid_Size_X", ""))]
+    with open(prefix + "_kernel_stats.csv", "w") as out:
+        out.write("kernel,calls,avg_us,min_us,max_us,total_us,vgpr,sgpr,lds_bytes,workgroup,grid\n")
+        for name, s in sorted(((k, v) for k, v in stats.items() if not k.endswith("|meta")), key=lambda kv: -kv[1][1]):
+            meta = stats.get(name + "|meta", [""] * 5)
+            out.write(f"\"{name}\",{s[0]},{s[1] / s[0]:.3f},{s[2]:.3f},{s[3]:.3f},{s[1]:.1f},{','.join(str(m) for m in meta)}\n")
+    pmc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            pmc[row.get("Kernel_Name", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    res = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in pmc.items()}
+    json.dump(res, open(prefix + "_pmc.json", "w"), indent=1, sort_keys=True)
+    print("wrote", prefix + "_kernel_stats.csv", prefix + "_pmc.json")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
