@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 control-flow rehearsal on a 1-GPU box: every rank uses cuda:0 and the gather goes "
+                         "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
     args = ap.parse_args()
 
     import torch
@@ -76,10 +79,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from opengl_raytracing_amd import dist as D
     from opengl_raytracing_amd import host, scenes
@@ -94,31 +102,37 @@ def main():
     strip_rows = args.strip_rows or D.default_strip_rows(H, world)
     plan = D.StripPlan(W, H, strip_rows, world) if world > 1 else D.StripPlan(W, H, H, 1)
     p = plan.params(base, rank) if world > 1 else base
-    rows = plan.max_local_rows if world > 1 else H
     dev = torch.device("cuda", local_rank)
-    s_col = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
-    s_pos = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
-    s_nrm = torch.empty((rows, W, 4), dtype=torch.float16, device=dev)
-    full = None
-    if world > 1 and rank == 0:
-        full = [torch.empty((H, W, 4), dtype=t.dtype, device=dev) for t in (s_col, s_pos, s_nrm)]
     # a dedicated (non-null) torch stream: the render kernel is launched on it through the ABI,
     # RCCL orders against it, and torch.cuda.Event timings see exactly these launches
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
+    # one packed buffer per rank: [gColor | gPosition | gNormal] for this rank's strips
+    rank_buf = D.alloc_rank_buffer(plan, dev)
+    s_col, s_pos, s_nrm = D.surface_views(rank_buf, plan)
+    gathered = full = None
+    if world > 1 and rank == 0:
+        gathered = torch.empty((world, plan.rank_bytes), dtype=torch.uint8, device=dev)
+        full = [torch.empty((H, W, 4), dtype=dt, device=dev) for dt in (torch.float32, torch.float32, torch.float16)]
 
     def step():
         rt.render_to(p, s_col.data_ptr(), s_pos.data_ptr(), s_nrm.data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            g = D.gather_strips([s_col, s_pos, s_nrm], plan, rank)
+        if world > 1 and args.rehearse_on_one_gpu:
+            stream.synchronize()
+            g = D.gather_rank_buffers(rank_buf.cpu(), plan, rank)
             if rank == 0:
-                for src, dst in zip(g, full):
-                    D.deinterleave_hip(rt, src, plan, out=dst, stream=stream.cuda_stream)
+                gathered.copy_(g)
+                D.deinterleave_hip(rt, gathered, plan, outs=full, stream=stream.cuda_stream)
+        elif world > 1:
+            g = D.gather_rank_buffers(rank_buf, plan, rank, out=gathered)   # ONE RCCL gather per frame
+            if rank == 0:
+                D.deinterleave_hip(rt, g, plan, outs=full, stream=stream.cuda_stream)
 
     # exact ray count of this rank's pixels (instrumented launch, outside the timed region)
     my_rays = rt.count_rays(p)
-    rays_t = torch.tensor([my_rays], dtype=torch.int64, device=dev)
+    red_dev = "cpu" if args.rehearse_on_one_gpu else dev
+    rays_t = torch.tensor([my_rays], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(rays_t)
     frame_rays = int(rays_t.item())
@@ -140,7 +154,7 @@ def main():
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -155,6 +169,18 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = kev0.elapsed_time(kev1) / args.steps
     step_ms_dev = ev0.elapsed_time(ev1) / args.steps
+
+    # untimed self-check at N > 1: the assembled frame must equal a single-GPU render bit for bit
+    assembled_ok = None
+    if world > 1 and rank == 0:
+        one = D.StripPlan(W, H, H, 1)
+        ref_buf = D.alloc_rank_buffer(one, dev)
+        rc, rp, rn = D.surface_views(ref_buf, one)
+        rt.render_to(base, rc.data_ptr(), rp.data_ptr(), rn.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        assembled_ok = bool(torch.equal(full[0].view(torch.int32), rc.view(torch.int32)) and
+                            torch.equal(full[1].view(torch.int32), rp.view(torch.int32)) and
+                            torch.equal(full[2].view(torch.int16), rn.view(torch.int16)))
 
     if rank == 0:
         n_px = W * H
@@ -183,7 +209,8 @@ def main():
                        "width": W, "height": H, "max_ray_depth": sc.max_ray_depth,
                        "parallelism": f"{world} x interleaved {strip_rows}-row strips + RCCL gather" if world > 1 else "1 GPU",
                        "rays_per_frame": frame_rays, "rays_per_pixel": round(frame_rays / n_px, 3)},
-            "mpx_per_s": round(n_px * args.steps / elapsed / 1e6, 1),
+            "mpx_per_s": round(n_px * args.steps / elapsed / 1e6, 1), "rehearsal": bool(args.rehearse_on_one_gpu),
+            "assembled_frame_equals_single_gpu_render": assembled_ok,
             "kernel_ms": round(kernel_ms, 4), "step_ms_device": round(step_ms_dev, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 3), "traffic": traffic,

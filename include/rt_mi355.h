@@ -184,11 +184,12 @@ int rt_scene_parse(const char *text, void *objects, int maxObj, int *nObj, void 
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);
-/* Rank-0 reassembly: src = stripCount packed strip buffers concatenated, each padded to
- * maxLocalRows rows of `width` pixels of bytesPerPixel; dst = full width x height image.
- * Device pointers; asynchronous on hipStream (NULL = the context's stream). */
+/* Rank-0 reassembly of gathered strip buffers.  src holds stripCount per-rank buffers,
+ * rankStrideBytes apart, each made of whole strips of `width` pixels of bytesPerPixel (rows in
+ * the rank's local order); dst = the full width x height image.  Device pointers;
+ * asynchronous on hipStream (NULL = the context's stream). */
 int rt_deinterleave(rt_context *ctx, const void *src, void *dst, int width, int height,
-                    int bytesPerPixel, int stripRows, int stripCount, int maxLocalRows,
+                    int bytesPerPixel, int stripRows, int stripCount, size_t rankStrideBytes,
                     void *hipStream);
 
 #ifdef __cplusplus

@@ -396,14 +396,15 @@ int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripInde
 }
 
 int rt_deinterleave(rt_context *c, const void *src, void *dst, int width, int height, int bytesPerPixel,
-                    int stripRows, int stripCount, int maxLocalRows, void *hipStream) {
+                    int stripRows, int stripCount, size_t rankStrideBytes, void *hipStream) {
     if (!c) return RT_ERR_INVALID_ARG;
-    if (!src || !dst || width <= 0 || height <= 0 || bytesPerPixel <= 0 || stripRows <= 0 || stripCount <= 0 || maxLocalRows <= 0)
+    if (!src || !dst || width <= 0 || height <= 0 || bytesPerPixel <= 0 || stripRows <= 0 || stripCount <= 0)
         return fail(c, RT_ERR_INVALID_ARG, "bad deinterleave arguments");
-    if (((size_t)width * bytesPerPixel) % 4 != 0) return fail(c, RT_ERR_INVALID_ARG, "row bytes must be a multiple of 4");
+    if (((size_t)width * bytesPerPixel) % 4 != 0 || rankStrideBytes % 4 != 0)
+        return fail(c, RT_ERR_INVALID_ARG, "row bytes and rank stride must be multiples of 4");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
-    HIP_TRY(c, rt_launch_deinterleave(src, dst, width, height, bytesPerPixel, stripRows, stripCount, maxLocalRows, s));
+    HIP_TRY(c, rt_launch_deinterleave(src, dst, width, height, bytesPerPixel, stripRows, stripCount, rankStrideBytes, s));
     return RT_OK;
 }
 

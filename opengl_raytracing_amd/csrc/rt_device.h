@@ -42,4 +42,4 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
                             uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s);
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
-                                  int stripRows, int stripCount, int maxLocalRows, hipStream_t s);
+                                  int stripRows, int stripCount, size_t rankStrideBytes, hipStream_t s);

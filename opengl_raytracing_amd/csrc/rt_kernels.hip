@@ -656,14 +656,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void rt_render_kernel(const RtFrame 
 // =========================================================================================
 template <typename U>
 __global__ void rt_deinterleave_kernel(const U *__restrict__ src, U *__restrict__ dst, int rowUnits,
-                                       int height, int stripRows, int stripCount, int maxLocalRows) {
+                                       int height, int stripRows, int stripCount, size_t rankStrideUnits) {
     const size_t total = (size_t)rowUnits * height;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
         int y = (int)(k / rowUnits), c = (int)(k % rowUnits);
         int strip = y / stripRows;
         int rank = strip % stripCount, localStrip = strip / stripCount;
         int ly = localStrip * stripRows + y % stripRows;
-        dst[k] = src[((size_t)rank * maxLocalRows + ly) * rowUnits + c];
+        dst[k] = src[(size_t)rank * rankStrideUnits + (size_t)ly * rowUnits + c];
     }
 }
 
@@ -690,24 +690,27 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
 }
 
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
-                                  int stripRows, int stripCount, int maxLocalRows, hipStream_t s) {
+                                  int stripRows, int stripCount, size_t rankStrideBytes, hipStream_t s) {
     size_t rowBytes = (size_t)width * bytesPerPixel;
-    // widest unit that divides a row: 16 B/lane for the rgba32f surfaces and even-width rgba16f
-    int unit = (rowBytes % 16 == 0) ? 16 : (rowBytes % 8 == 0) ? 8 : (rowBytes % 4 == 0) ? 4 : 0;
+    // widest unit that divides a row, the rank stride and both base addresses: 16 B/lane for
+    // the rgba32f surfaces (and rgba16f at even widths)
+    size_t all = rowBytes | rankStrideBytes | (size_t)(uintptr_t)src | (size_t)(uintptr_t)dst;
+    int unit = (all % 16 == 0) ? 16 : (all % 8 == 0) ? 8 : (all % 4 == 0) ? 4 : 0;
     if (!unit) return hipErrorInvalidValue;
     int rowUnits = (int)(rowBytes / unit);
+    size_t strideUnits = rankStrideBytes / unit;
     size_t total = (size_t)rowUnits * height;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     if (unit == 16)
         hipLaunchKernelGGL(rt_deinterleave_kernel<uint4>, dim3(blocks), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst,
-                           rowUnits, height, stripRows, stripCount, maxLocalRows);
+                           rowUnits, height, stripRows, stripCount, strideUnits);
     else if (unit == 8)
         hipLaunchKernelGGL(rt_deinterleave_kernel<uint2>, dim3(blocks), dim3(256), 0, s, (const uint2 *)src, (uint2 *)dst,
-                           rowUnits, height, stripRows, stripCount, maxLocalRows);
+                           rowUnits, height, stripRows, stripCount, strideUnits);
     else
         hipLaunchKernelGGL(rt_deinterleave_kernel<unsigned>, dim3(blocks), dim3(256), 0, s, (const unsigned *)src,
-                           (unsigned *)dst, rowUnits, height, stripRows, stripCount, maxLocalRows);
+                           (unsigned *)dst, rowUnits, height, stripRows, stripCount, strideUnits);
     return hipGetLastError();
 }

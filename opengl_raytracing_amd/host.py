@@ -78,7 +78,7 @@ def load_library(build_if_missing=True):
     lib.rt_camera_vectors.argtypes = [ctypes.c_float, ctypes.c_float, P(ctypes.c_float), P(ctypes.c_float), P(ctypes.c_float)]
     lib.rt_scene_parse.argtypes = [ctypes.c_char_p, vp, ci, P(ci), vp, ci, P(ci)]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
-    lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     for name in EXPORTS:
         if name != "rt_last_error":
             getattr(lib, name).restype = ci
@@ -224,7 +224,7 @@ class RayTracer:
         return n.value
 
     def deinterleave(self, d_src, d_dst, width, height, bytes_per_pixel, strip_rows, strip_count,
-                     max_local_rows, stream=None):
+                     rank_stride_bytes, stream=None):
         self._check(self.lib.rt_deinterleave(self.ctx, ctypes.c_void_p(d_src), ctypes.c_void_p(d_dst), width,
-                                             height, bytes_per_pixel, strip_rows, strip_count, max_local_rows,
+                                             height, bytes_per_pixel, strip_rows, strip_count, rank_stride_bytes,
                                              ctypes.c_void_p(stream) if stream else None), "rt_deinterleave")

@@ -189,21 +189,19 @@ def test_strip_tiling_equals_single_render(tracer, host):
     col, pos, nrm = render_gpu(tracer, sc, base)
     for world, strip_rows in [(2, 16), (4, 16), (8, 8), (3, 32)]:
         plan = D.StripPlan(322, 187, strip_rows, world)
-        n = plan.max_local_rows
-        gc = torch.empty((world * n, 322, 4), dtype=torch.float32, device="cuda")
-        gp = torch.empty_like(gc)
-        gn = torch.empty((world * n, 322, 4), dtype=torch.float16, device="cuda")
+        gathered = torch.empty((world, plan.rank_bytes), dtype=torch.uint8, device="cuda")
         for r in range(world):
-            pr = plan.params(base, r)
-            tracer.render_to(pr, gc[r * n:].data_ptr(), gp[r * n:].data_ptr(), gn[r * n:].data_ptr())
+            vc, vp, vn = D.surface_views(gathered[r], plan)
+            tracer.render_to(plan.params(base, r), vc.data_ptr(), vp.data_ptr(), vn.data_ptr())
         tracer.sync()
-        for gathered, ref in [(gc, col), (gp, pos), (gn, nrm)]:
-            out = D.deinterleave_hip(tracer, gathered, plan)
-            tracer.sync()
-            torch.cuda.synchronize()
+        outs = D.deinterleave_hip(tracer, gathered, plan)
+        tracer.sync()
+        torch.cuda.synchronize()
+        check = D.deinterleave_torch(gathered, plan)
+        for out, chk, ref in zip(outs, check, (col, pos, nrm)):
             assert bits_equal(out.cpu().numpy(), ref), f"world {world}"
-            assert torch.equal(D.deinterleave_torch(gathered, plan).view(torch.int16 if gathered.dtype == torch.float16 else torch.int32),
-                               out.view(torch.int16 if gathered.dtype == torch.float16 else torch.int32))
+            it = torch.int16 if out.dtype == torch.float16 else torch.int32
+            assert torch.equal(out.view(it), chk.view(it))
 
 
 def test_scene_update_every_frame_and_timing(tracer, host, oracle):
