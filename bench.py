@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index 1..5 (default 2 = the metric's)")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=1, help="1 = packet kernel (default), 0 = exhaustive loop")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 control-flow rehearsal on a 1-GPU box: every rank uses cuda:0 and the gather goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")

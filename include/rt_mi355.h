@@ -165,9 +165,15 @@ int rt_last_kernel_ms(rt_context *ctx, float *ms);
  * counted by an instrumented build of the same kernel.  Synchronises. */
 int rt_count_rays(rt_context *ctx, const rt_params *p, uint64_t *rays);
 
-/* Kernel variant: 0 = default.  Variants exist for A/B measurements only and all
- * produce identical surfaces. */
+/* Kernel variant: 1 (default) = wavefront-packet kernel (packet culling, scalar-fed traversal),
+ * 0 = exhaustive per-lane loop over all objects.  Both produce bit-identical surfaces; the switch
+ * exists for A/B measurements and as a cross-check in the tests. */
 int rt_set_variant(rt_context *ctx, int variant);
+
+/* Diagnostics of the last rt_count_rays launch: out[0] rays, out[1] wave-level ray packets,
+ * out[2] candidate objects summed over packets (after packet culling), out[3] 64-object cull
+ * passes.  [1..3] are zero for variant 0 (no packet culling). */
+int rt_debug_stats(rt_context *ctx, uint64_t out[4]);
 
 const char *rt_last_error(rt_context *ctx);
 

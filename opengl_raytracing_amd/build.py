@@ -16,7 +16,7 @@ ORACLE_DIR = os.path.join(REPO, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle_rt.so")
 
 SOURCES = ["rt_kernels.hip", "rt_abi.cpp", "rt_host.cpp"]
-HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(REPO, "include", "rt_mi355.h")]
+HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_packet.inc"), os.path.join(REPO, "include", "rt_mi355.h")]
 
 # -ffp-contract=off: the reference's GL never fuses a*b+c; IEEE divide and
 # sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
@@ -41,16 +41,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True, extra_flags=()):
+def build_library(force=False, verbose=True, extra_flags=(), out=None):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not force and not _stale(LIB_PATH, srcs + HEADERS + [os.path.abspath(__file__)]):
-        return LIB_PATH
+    out = out or LIB_PATH
+    if not force and not _stale(out, srcs + HEADERS + [os.path.abspath(__file__)]):
+        return out
     cmd = [_hipcc(), *HIPCC_FLAGS, *extra_flags, "-I", os.path.join(REPO, "include"), "-I", CSRC,
-           "-x", "hip", *srcs, "-o", LIB_PATH]
+           "-x", "hip", *srcs, "-o", out]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 def build_oracle(force=False, verbose=True):

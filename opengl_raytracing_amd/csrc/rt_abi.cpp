@@ -41,7 +41,8 @@ struct rt_context {
     size_t capPixels = 0;
     int surfW = 0, surfH = 0;
     unsigned long long *dRayCounter = nullptr;
-    int variant = 0;
+    int variant = 1;   // 1 = wavefront-packet kernel (default), 0 = exhaustive per-lane loop
+    unsigned long long lastStats[4] = {0, 0, 0, 0};   // rt_count_rays diagnostics (rt_debug_stats)
     std::string err;
 };
 
@@ -170,7 +171,7 @@ int rt_create(rt_context **out, int deviceId) {
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
         hipEventCreateWithFlags(&c->evScene, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evForeign, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&c->dRayCounter, sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void **)&c->dRayCounter, 4 * sizeof(unsigned long long)) != hipSuccess) {
         rt_destroy(c);
         return RT_ERR_HIP;
     }
@@ -359,13 +360,14 @@ int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) {
     hipError_t e2 = hipMalloc((void **)&nrm, n * sizeof(uint2));
     if (e1 == hipSuccess && e2 == hipSuccess) {
         rc = RT_OK;
-        if (hipMemsetAsync(c->dRayCounter, 0, sizeof(unsigned long long), c->stream) != hipSuccess) rc = RT_ERR_HIP;
+        if (hipMemsetAsync(c->dRayCounter, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = RT_ERR_HIP;
         if (!rc) rc = launch(c, p, col, pos, nrm, c->dRayCounter, c->stream, false);
-        unsigned long long v = 0;
+        unsigned long long v[4] = {0, 0, 0, 0};
         if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess ||
-                    hipMemcpy(&v, c->dRayCounter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess))
+                    hipMemcpy(v, c->dRayCounter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess))
             rc = fail(c, RT_ERR_HIP, "ray counter readback");
-        *rays = v;
+        *rays = v[0];
+        for (int k = 0; k < 4; k++) c->lastStats[k] = v[k];
     } else {
         rc = fail(c, RT_ERR_HIP, "hipMalloc (ray count scratch)", e1 != hipSuccess ? e1 : e2);
     }
@@ -378,6 +380,12 @@ int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) {
 int rt_set_variant(rt_context *c, int variant) {
     if (!c) return RT_ERR_INVALID_ARG;
     c->variant = variant;
+    return RT_OK;
+}
+
+int rt_debug_stats(rt_context *c, uint64_t out[4]) {
+    if (!c || !out) return RT_ERR_INVALID_ARG;
+    for (int k = 0; k < 4; k++) out[k] = c->lastStats[k];
     return RT_OK;
 }
 

@@ -115,6 +115,9 @@ struct SceneLds {
     const float4 *lgt;     // nLt  * RT_LGT_F4
     const float *halton2;  // RT_HALTON_N
     const float *halton3;  // RT_HALTON_N
+    unsigned long long *stats = nullptr;   // diagnostic counters (instrumented build only)
+    const float4 *global = nullptr;        // the same records in global memory (scalar-load path)
+    int lgtF4Base = 0, haltonFloatBase = 0;   // offsets of the light / Halton sections (float4 / float units)
 };
 
 // haltonSequence (raytracingCs.glsl:278-288); used by the scene compiler and as the
@@ -470,6 +473,8 @@ __device__ __forceinline__ float random2(float sx, float sy) {
     return fract(det_sinf(d) * 43758.5453123f);
 }
 
+#include "rt_packet.inc"
+
 }  // namespace
 
 // =========================================================================================
@@ -529,8 +534,16 @@ __global__ void rt_compile_scene_kernel(const uint8_t *objects, int nObj, const 
 // =========================================================================================
 // Render kernel: main() of raytracingCs.glsl (:509-584), one lane per pixel.
 // =========================================================================================
+#ifndef RT_V0_WAVES
+#define RT_V0_WAVES 0
+#endif
+#if RT_V0_WAVES > 0
+#define RT_V0_BOUNDS __launch_bounds__(BLOCK_THREADS, RT_V0_WAVES)
+#else
+#define RT_V0_BOUNDS __launch_bounds__(BLOCK_THREADS)
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK_THREADS) void rt_render_kernel(const RtFrame f, const RtDeviceScene dsc,
+__global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceScene dsc,
                                                                   float4 *__restrict__ gColor,
                                                                   float4 *__restrict__ gPosition,
                                                                   uint2 *__restrict__ gNormal,
@@ -652,6 +665,60 @@ __global__ __launch_bounds__(BLOCK_THREADS) void rt_render_kernel(const RtFrame 
 }
 
 // =========================================================================================
+// Render kernel, wavefront-packet variant (rt_packet.inc): same staging and lane->pixel map.
+// =========================================================================================
+#ifndef RT_PK_WAVES
+#define RT_PK_WAVES 5       // __launch_bounds__ waves per SIMD (0 = allocator's choice).  Measured on C2..C5:
+                            // the kernel is latency-bound; 5 waves (96 VGPRs, 84 B/lane scratch) beat 4 (no scratch), 6 and 8.
+#endif
+#if RT_PK_WAVES > 0
+#define RT_PK_BOUNDS __launch_bounds__(BLOCK_THREADS, RT_PK_WAVES)
+#else
+#define RT_PK_BOUNDS __launch_bounds__(BLOCK_THREADS)
+#endif
+template <bool COUNT>
+__global__ RT_PK_BOUNDS void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc,
+                                                                         float4 *__restrict__ gColor,
+                                                                         float4 *__restrict__ gPosition,
+                                                                         uint2 *__restrict__ gNormal,
+                                                                         unsigned long long *rayCounter) {
+    extern __shared__ float4 lds[];
+    const int nF4 = f.nObj * (RT_HOT_F4 + RT_MAT_F4) + f.nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
+    for (int i = threadIdx.x; i < nF4; i += BLOCK_THREADS) lds[i] = dsc.compiled[i];
+    __syncthreads();
+    SceneLds sc;
+    sc.hot = lds;
+    sc.mat = sc.hot + f.nObj * RT_HOT_F4;
+    sc.lgt = sc.mat + f.nObj * RT_MAT_F4;
+    sc.halton2 = (const float *)(sc.lgt + f.nLt * RT_LGT_F4);
+    sc.halton3 = sc.halton2 + RT_HALTON_N;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
+    const int j = blockIdx.y * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inWindow = i < f.p.regionW && j < f.p.regionH;
+    const int gxI = f.p.x0 + i;
+    const int ly = f.p.y0 + j;
+    const int gyI = ((ly / f.p.stripRows) * f.p.stripCount + f.p.stripIndex) * f.p.stripRows + ly % f.p.stripRows;
+    const size_t outIdx = (size_t)j * f.p.regionW + i;
+    unsigned rays = 0;
+    sc.stats = COUNT ? rayCounter : nullptr;
+    sc.global = dsc.compiled;
+    sc.lgtF4Base = f.nObj * (RT_HOT_F4 + RT_MAT_F4);
+    sc.haltonFloatBase = (sc.lgtF4Base + f.nLt * RT_LGT_F4) * 4;
+    render_packet<COUNT>(f, dsc, sc, inWindow, gxI, gyI, outIdx, gColor, gPosition, gNormal, rays);
+
+    if (COUNT) {
+        unsigned long long *blockRays = (unsigned long long *)(lds + nF4);
+        if (threadIdx.x == 0) *blockRays = 0ull;
+        __syncthreads();
+        atomicAdd(blockRays, (unsigned long long)rays);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(rayCounter, *blockRays);
+    }
+}
+
+// =========================================================================================
 // Rank-0 reassembly of gathered interleaved strips (multi-GPU): pure copy kernel, 16 B/lane.
 // =========================================================================================
 template <typename U>
@@ -678,14 +745,20 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
                             uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s) {
-    (void)variant;
     if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
     dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
     size_t ldsBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
-    if (dRayCounter)
-        hipLaunchKernelGGL(rt_render_kernel<true>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-    else
-        hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+    if (variant == 1) {
+        if (dRayCounter)
+            hipLaunchKernelGGL(rt_render_packet_kernel<true>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        else
+            hipLaunchKernelGGL(rt_render_packet_kernel<false>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+    } else {
+        if (dRayCounter)
+            hipLaunchKernelGGL(rt_render_kernel<true>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        else
+            hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+    }
     return hipGetLastError();
 }
 

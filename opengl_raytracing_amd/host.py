@@ -31,7 +31,7 @@ _LIB = None
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
-    "rt_count_rays", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
+    "rt_count_rays", "rt_debug_stats", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_strip_local_rows", "rt_deinterleave",
 ]
 
@@ -51,7 +51,7 @@ def load_library(build_if_missing=True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB_PATH
+    path = os.environ.get("RT_LIB", _build.LIB_PATH)   # RT_LIB: experiment builds (tests/gpu_explore.py)
     if not os.path.exists(path):
         if not build_if_missing:
             raise RtError(-2, f"{path} not built (run python -m opengl_raytracing_amd.build)")
@@ -72,6 +72,7 @@ def load_library(build_if_missing=True):
     lib.rt_last_kernel_ms.argtypes = [vp, P(ctypes.c_float)]
     lib.rt_count_rays.argtypes = [vp, P(L.RtParams), P(ctypes.c_uint64)]
     lib.rt_set_variant.argtypes = [vp, ci]
+    lib.rt_debug_stats.argtypes = [vp, P(ctypes.c_uint64)]
     lib.rt_last_error.argtypes = [vp]
     lib.rt_last_error.restype = ctypes.c_char_p
     lib.rt_generate_aabb.argtypes = [vp, ci]
@@ -138,6 +139,9 @@ class RayTracer:
             self.ctx = None
             raise RtError(rc, "rt_create (is a HIP device present?)")
         self._region = None
+        v = int(os.environ.get("RT_VARIANT", "-1"))   # A/B switch for measurements and tests
+        if v >= 0:
+            self.set_variant(v)
 
     def _check(self, rc, what):
         if rc:
@@ -222,6 +226,11 @@ class RayTracer:
         n = ctypes.c_uint64()
         self._check(self.lib.rt_count_rays(self.ctx, ctypes.byref(params), ctypes.byref(n)), "rt_count_rays")
         return n.value
+
+    def debug_stats(self):
+        out = (ctypes.c_uint64 * 4)()
+        self._check(self.lib.rt_debug_stats(self.ctx, out), "rt_debug_stats")
+        return list(out)
 
     def deinterleave(self, d_src, d_dst, width, height, bytes_per_pixel, strip_rows, strip_count,
                      rank_stride_bytes, stream=None):

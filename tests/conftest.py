@@ -102,9 +102,12 @@ def host():
     return h
 
 
-@pytest.fixture(scope="session")
-def tracer(host):
-    """One device context for the whole GPU session (fails loudly if the HIP path is unusable)."""
+@pytest.fixture(scope="session", params=[1, 0], ids=["packet", "exhaustive"])
+def tracer(host, request):
+    """One device context per kernel variant for the whole GPU session (fails loudly if the HIP
+    path is unusable).  Every parity test runs against both the default wavefront-packet kernel
+    (variant 1) and the exhaustive per-lane loop (variant 0)."""
     rt = host.RayTracer(0)
+    rt.set_variant(request.param)
     yield rt
     rt.close()
