@@ -33,6 +33,20 @@ def main(src, prefix):
     res = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in pmc.items()}
     json.dump(res, open(prefix + "_pmc.json", "w"), indent=1, sort_keys=True)
     print("wrote", prefix + "_kernel_stats.csv", prefix + "_pmc.json")
+    # HBM traffic of the dominant render kernel, per launch, for bench.py's roofline.traffic:
+    # (2*FETCH_SIZE + WRITE_SIZE) KB -- MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B
+    # request on gfx950 (exact for wide streaming reads, an upper bound otherwise); WRITE_SIZE exact.
+    cfg = os.environ.get("RT_PROFILE_CFG", "c2")
+    for k, cs in res.items():
+        if ("render_packet_kernel<false>" in k or "render_kernel<false>" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            tpath = os.path.join(os.path.dirname(prefix), "traffic.json")
+            t = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            t[cfg] = {"hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024),
+                      "fetch_size_kb": cs["FETCH_SIZE"]["mean"], "write_size_kb": cs["WRITE_SIZE"]["mean"],
+                      "kernel": k.split("(")[0], "source": os.path.basename(prefix) + "_pmc.json"}
+            json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
+            print("wrote", tpath)
+            break
 
 
 if __name__ == "__main__":
