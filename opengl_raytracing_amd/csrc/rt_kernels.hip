@@ -24,8 +24,8 @@
 #include <hip/hip_fp16.h>
 
 #define WAVE 64
-#define TILE 16           // workgroup tile edge in pixels
-#define BLOCK_THREADS 256
+#define BLOCK_THREADS 256 // exhaustive kernel: four waves, 16x16-pixel workgroup tile
+#define TILE 16
 
 namespace {
 
@@ -117,6 +117,7 @@ struct SceneLds {
     const float *halton3;  // RT_HALTON_N
     unsigned long long *stats = nullptr;   // diagnostic counters (instrumented build only)
     const float4 *global = nullptr;        // the same records in global memory (scalar-load path)
+    float *park = nullptr;                 // per-thread LDS parking area, 9 floats x BLOCK_THREADS (packet kernel)
     int lgtF4Base = 0, haltonFloatBase = 0;   // offsets of the light / Halton sections (float4 / float units)
 };
 
@@ -667,24 +668,27 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 // =========================================================================================
 // Render kernel, wavefront-packet variant (rt_packet.inc): same staging and lane->pixel map.
 // =========================================================================================
-#ifndef RT_PK_WAVES
-#define RT_PK_WAVES 5       // __launch_bounds__ waves per SIMD (0 = allocator's choice).  Measured on C2..C5:
-                            // the kernel is latency-bound; 5 waves (96 VGPRs, 84 B/lane scratch) beat 4 (no scratch), 6 and 8.
+// Two instantiations: 64-thread workgroups (one wave, 8x8 tile; finer-grained scheduling, no
+// intra-group imbalance, 112 VGPRs / 4 waves per SIMD with NO scratch) for small scenes, where
+// staging the compiled scene per wave is cheap, and 256-thread workgroups (16x16 tile, staging
+// amortised over four waves, 5 waves per SIMD) for larger ones.  Measured in DESIGN.md.
+#ifndef RT_PK_WAVES_SMALL
+#define RT_PK_WAVES_SMALL 4
 #endif
-#if RT_PK_WAVES > 0
-#define RT_PK_BOUNDS __launch_bounds__(BLOCK_THREADS, RT_PK_WAVES)
-#else
-#define RT_PK_BOUNDS __launch_bounds__(BLOCK_THREADS)
+#ifndef RT_PK_WAVES_LARGE
+#define RT_PK_WAVES_LARGE 5
 #endif
-template <bool COUNT>
-__global__ RT_PK_BOUNDS void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc,
-                                                                         float4 *__restrict__ gColor,
-                                                                         float4 *__restrict__ gPosition,
-                                                                         uint2 *__restrict__ gNormal,
-                                                                         unsigned long long *rayCounter) {
+#ifndef RT_PK_SMALL_SCENE
+#define RT_PK_SMALL_SCENE 32    // objects: at or below, use the one-wave workgroup
+#endif
+template <bool COUNT, int BT>
+__global__ __launch_bounds__(BT, (BT == 64 ? RT_PK_WAVES_SMALL : RT_PK_WAVES_LARGE))
+void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
+                             float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
+                             unsigned long long *rayCounter) {
     extern __shared__ float4 lds[];
     const int nF4 = f.nObj * (RT_HOT_F4 + RT_MAT_F4) + f.nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
-    for (int i = threadIdx.x; i < nF4; i += BLOCK_THREADS) lds[i] = dsc.compiled[i];
+    for (int i = threadIdx.x; i < nF4; i += BT) lds[i] = dsc.compiled[i];
     __syncthreads();
     SceneLds sc;
     sc.hot = lds;
@@ -692,21 +696,14 @@ __global__ RT_PK_BOUNDS void rt_render_packet_kernel(const RtFrame f, const RtDe
     sc.lgt = sc.mat + f.nObj * RT_MAT_F4;
     sc.halton2 = (const float *)(sc.lgt + f.nLt * RT_LGT_F4);
     sc.halton3 = sc.halton2 + RT_HALTON_N;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
-    const int j = blockIdx.y * TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inWindow = i < f.p.regionW && j < f.p.regionH;
-    const int gxI = f.p.x0 + i;
-    const int ly = f.p.y0 + j;
-    const int gyI = ((ly / f.p.stripRows) * f.p.stripCount + f.p.stripIndex) * f.p.stripRows + ly % f.p.stripRows;
-    const size_t outIdx = (size_t)j * f.p.regionW + i;
-    unsigned rays = 0;
     sc.stats = COUNT ? rayCounter : nullptr;
     sc.global = dsc.compiled;
     sc.lgtF4Base = f.nObj * (RT_HOT_F4 + RT_MAT_F4);
     sc.haltonFloatBase = (sc.lgtF4Base + f.nLt * RT_LGT_F4) * 4;
-    render_packet<COUNT>(f, dsc, sc, inWindow, gxI, gyI, outIdx, gColor, gPosition, gNormal, rays);
+    sc.park = (float *)(lds + nF4 + 1);      // after the scene and the 16-byte counter slot
+
+    unsigned rays = 0;
+    render_packet<COUNT, BT>(f, dsc, sc, gColor, gPosition, gNormal, rays);
 
     if (COUNT) {
         unsigned long long *blockRays = (unsigned long long *)(lds + nF4);
@@ -746,18 +743,25 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
                             uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s) {
     if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
-    dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
-    size_t ldsBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
+    const size_t sceneBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
     if (variant == 1) {
-        if (dRayCounter)
-            hipLaunchKernelGGL(rt_render_packet_kernel<true>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-        else
-            hipLaunchKernelGGL(rt_render_packet_kernel<false>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        const bool small = f.nObj <= RT_PK_SMALL_SCENE;
+        const int bt = small ? 64 : 256, tile = small ? 8 : 16;
+        dim3 grid((f.p.regionW + tile - 1) / tile, (f.p.regionH + tile - 1) / tile);
+        const size_t ldsBytes = sceneBytes + 9 * bt * sizeof(float);                    // + the parking area
+        if (small) {
+            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        } else {
+            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 256>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 256>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        }
     } else {
+        dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
         if (dRayCounter)
-            hipLaunchKernelGGL(rt_render_kernel<true>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            hipLaunchKernelGGL(rt_render_kernel<true>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         else
-            hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
     }
     return hipGetLastError();
 }

@@ -38,7 +38,7 @@ def main(src, prefix):
     # request on gfx950 (exact for wide streaming reads, an upper bound otherwise); WRITE_SIZE exact.
     cfg = os.environ.get("RT_PROFILE_CFG", "c2")
     for k, cs in res.items():
-        if ("render_packet_kernel<false>" in k or "render_kernel<false>" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        if ("render_packet_kernel<false" in k or "render_kernel<false" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             tpath = os.path.join(os.path.dirname(prefix), "traffic.json")
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
             t[cfg] = {"hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024),
