@@ -103,31 +103,56 @@ def main():
     plan = D.StripPlan(W, H, strip_rows, world) if world > 1 else D.StripPlan(W, H, H, 1)
     p = plan.params(base, rank) if world > 1 else base
     dev = torch.device("cuda", local_rank)
-    # a dedicated (non-null) torch stream: the render kernel is launched on it through the ABI,
-    # RCCL orders against it, and torch.cuda.Event timings see exactly these launches
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    # one packed buffer per rank: [gColor | gPosition | gNormal] for this rank's strips
-    rank_buf = D.alloc_rank_buffer(plan, dev)
-    s_col, s_pos, s_nrm = D.surface_views(rank_buf, plan)
-    gathered = full = None
+    # Two dedicated (non-null) torch streams.  The render kernel is launched on `s_render` through
+    # the ABI; at N > 1 the RCCL gather and the re-assembly kernels are issued from `s_comm`.
+    # Frames are double-buffered, so frame k's gather (xGMI) overlaps frame k+1's render (compute):
+    #   s_render:  [wait gather k-2] render k -> E_render[k%2]
+    #   s_comm  :  wait E_render[k%2]; gather k; deinterleave k -> E_gather[k%2]
+    # The timed region still brackets K complete frames (render + gather + re-assembly, drained).
+    s_render = torch.cuda.Stream(device=dev)
+    s_comm = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(s_render)
+    assert s_render.cuda_stream != 0 and s_comm.cuda_stream != 0
+    stream = s_render
+    # one packed buffer per rank and pipeline slot: [gColor | gPosition | gNormal] of this rank's strips
+    rank_bufs = [D.alloc_rank_buffer(plan, dev) for _ in range(2 if world > 1 else 1)]
+    views = [D.surface_views(b, plan) for b in rank_bufs]
+    rank_buf = rank_bufs[0]
+    s_col, s_pos, s_nrm = views[0]
+    gathered = [None, None]
+    full = None
     if world > 1 and rank == 0:
-        gathered = torch.empty((world, plan.rank_bytes), dtype=torch.uint8, device=dev)
+        gathered = [torch.empty((world, plan.rank_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         full = [torch.empty((H, W, 4), dtype=dt, device=dev) for dt in (torch.float32, torch.float32, torch.float16)]
+    ev_render = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_gather = [torch.cuda.Event(), torch.cuda.Event()]
+    frame_no = [0]
 
     def step():
-        rt.render_to(p, s_col.data_ptr(), s_pos.data_ptr(), s_nrm.data_ptr(), stream=stream.cuda_stream)
-        if world > 1 and args.rehearse_on_one_gpu:
-            stream.synchronize()
-            g = D.gather_rank_buffers(rank_buf.cpu(), plan, rank)
-            if rank == 0:
-                gathered.copy_(g)
-                D.deinterleave_hip(rt, gathered, plan, outs=full, stream=stream.cuda_stream)
-        elif world > 1:
-            g = D.gather_rank_buffers(rank_buf, plan, rank, out=gathered)   # ONE RCCL gather per frame
-            if rank == 0:
-                D.deinterleave_hip(rt, g, plan, outs=full, stream=stream.cuda_stream)
+        k = frame_no[0]
+        frame_no[0] += 1
+        if world == 1:
+            rt.render_to(p, s_col.data_ptr(), s_pos.data_ptr(), s_nrm.data_ptr(), stream=s_render.cuda_stream)
+            return
+        b = k & 1
+        c, q, n = views[b]
+        if k >= 2:
+            s_render.wait_event(ev_gather[b])        # slot b's previous frame has left the buffer
+        rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=s_render.cuda_stream)
+        ev_render[b].record(s_render)
+        with torch.cuda.stream(s_comm):
+            s_comm.wait_event(ev_render[b])
+            if args.rehearse_on_one_gpu:
+                s_comm.synchronize()
+                g = D.gather_rank_buffers(rank_bufs[b].cpu(), plan, rank)
+                if rank == 0:
+                    gathered[b].copy_(g)
+                    D.deinterleave_hip(rt, gathered[b], plan, outs=full, stream=s_comm.cuda_stream)
+            else:
+                g = D.gather_rank_buffers(rank_bufs[b], plan, rank, out=gathered[b])   # ONE RCCL gather per frame
+                if rank == 0:
+                    D.deinterleave_hip(rt, g, plan, outs=full, stream=s_comm.cuda_stream)
+            ev_gather[b].record(s_comm)
 
     # exact ray count of this rank's pixels (instrumented launch, outside the timed region)
     my_rays = rt.count_rays(p)
@@ -151,6 +176,8 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    if world > 1:
+        s_render.wait_stream(s_comm)      # the last frame's gather + re-assembly belongs to the timed region
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
@@ -207,7 +234,7 @@ def main():
                                    f"{len(sc.lights)} lights, depth {sc.max_ray_depth}, "
                                    f"{'PCSS' if int(sc.lights['shadowType'][0]) == 2 else 'PCF x4'} shadows",
                        "width": W, "height": H, "max_ray_depth": sc.max_ray_depth,
-                       "parallelism": f"{world} x interleaved {strip_rows}-row strips + RCCL gather" if world > 1 else "1 GPU",
+                       "parallelism": f"{world} x interleaved {strip_rows}-row strips + one RCCL gather/frame, gather k overlapped with render k+1" if world > 1 else "1 GPU",
                        "rays_per_frame": frame_rays, "rays_per_pixel": round(frame_rays / n_px, 3)},
             "mpx_per_s": round(n_px * args.steps / elapsed / 1e6, 1), "rehearsal": bool(args.rehearse_on_one_gpu),
             "assembled_frame_equals_single_gpu_render": assembled_ok,

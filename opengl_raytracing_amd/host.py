@@ -51,7 +51,7 @@ def load_library(build_if_missing=True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.environ.get("RT_LIB", _build.LIB_PATH)   # RT_LIB: experiment builds (tests/gpu_explore.py)
+    path = os.environ.get("RT_LIB", _build.LIB_PATH)   # RT_LIB: experiment builds (tools/gpu_explore.py)
     if not os.path.exists(path):
         if not build_if_missing:
             raise RtError(-2, f"{path} not built (run python -m opengl_raytracing_amd.build)")

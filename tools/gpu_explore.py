@@ -1,5 +1,5 @@
 """Build several macro variants of the library ON the GPU box and time them in one gpurun call.
-usage: python tests/gpu_explore.py "name1:-DX=1 -DY=2" "name2:..."  [--cfgs=2,3]"""
+usage: python tools/gpu_explore.py "name1:-DX=1 -DY=2" "name2:..."  [--cfgs=2,3]"""
 import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -26,7 +26,7 @@ for spec in specs:
             vg, sc_, oc, sp = g("VGPRs"), g("ScratchSize .bytes.lane."), g("Occupancy .waves.SIMD."), g("SGPRs Spill")
             print(f"[{name}] {b_[:30]}: VGPR {vg} scratch {sc_} occ {oc} sgprspill {sp}", flush=True)
     env = dict(os.environ, RT_LIB=out)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "gpu_ab.py"), os.environ.get("RT_AB_VARIANTS", "1"), cfgs], env=env, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gpu_ab.py"), os.environ.get("RT_AB_VARIANTS", "1"), cfgs], env=env, capture_output=True, text=True)
     lines = [l for l in r.stdout.splitlines() if l.startswith("cfg")]
     for l in lines[1::2]:
         print(f"[{name}] {l[:118]}", flush=True)
