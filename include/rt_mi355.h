@@ -187,6 +187,15 @@ int rt_camera_vectors(float yawDeg, float pitchDeg, float front[3], float right[
 int rt_scene_parse(const char *text, void *objects, int maxObj, int *nObj, void *lights,
                    int maxLt, int *nLt);
 
+/* SceneIO::Save's writer (/root/reference/src/SceneIO.h:50-73, 124-142) into a caller buffer:
+ * one "OBJECT <TYPE> <name> 18 numbers" / "LIGHT <TYPE> <name> 12 numbers" line per record, default
+ * ostream float formatting.  Names may be NULL ("Object<i>" / "Light<i>").  *needed receives the
+ * size including the terminator; out == NULL only queries it; too small -> RT_ERR_TOO_LARGE.
+ * Lossy exactly like the reference's format (diffuseStrength, subsurface*, shadow fields are not stored). */
+int rt_scene_write(const void *objects, int nObj, const void *lights, int nLt,
+                   const char *const *objNames, const char *const *lightNames, char *out,
+                   size_t cap, size_t *needed);
+
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);

@@ -149,4 +149,37 @@ int rt_scene_parse(const char *text, void *objects, int maxObj, int *nObj, void 
     return RT_OK;
 }
 
+int rt_scene_write(const void *objects, int nObj, const void *lights, int nLt, const char *const *objNames,
+                   const char *const *lightNames, char *out, size_t cap, size_t *needed) {
+    if (nObj < 0 || nLt < 0 || (nObj > 0 && !objects) || (nLt > 0 && !lights) || !needed) return RT_ERR_INVALID_ARG;
+    const rt_object *objs = (const rt_object *)objects;
+    const rt_light *lts = (const rt_light *)lights;
+    std::ostringstream file;   // same default float formatting as the std::ofstream of SceneIO::Save
+    for (int i = 0; i < nObj; i++) {   // WriteObjectParams (SceneIO.h:50-64)
+        const rt_object &o = objs[i];
+        std::string name = (objNames && objNames[i]) ? objNames[i] : ("Object" + std::to_string(i));
+        file << "OBJECT " << (o.type == 0 ? "SPHERE" : o.type == 1 ? "PLANE" : "UNKNOWN");
+        file << " " << name << " " << o.position[0] << " " << o.position[1] << " " << o.position[2] << " " << o.radius << " "
+             << o.normal[0] << " " << o.normal[1] << " " << o.normal[2] << " " << o.size[0] << " " << o.size[1] << " "
+             << o.material.type << " " << o.material.albedo[0] << " " << o.material.albedo[1] << " " << o.material.albedo[2]
+             << " " << o.material.metallic << " " << o.material.roughness << " " << o.material.ior << " "
+             << o.material.transparency << " " << o.material.specular;
+        file << "\n";
+    }
+    for (int i = 0; i < nLt; i++) {    // WriteLightParams (SceneIO.h:66-73)
+        const rt_light &l = lts[i];
+        std::string name = (lightNames && lightNames[i]) ? lightNames[i] : ("Light" + std::to_string(i));
+        file << "LIGHT " << (l.type == 1 ? "DIRECTIONAL" : l.type == 2 ? "AREA" : "POINT");
+        file << " " << name << " " << l.position[0] << " " << l.position[1] << " " << l.position[2] << " " << l.direction[0]
+             << " " << l.direction[1] << " " << l.direction[2] << " " << l.color[0] << " " << l.color[1] << " " << l.color[2]
+             << " " << l.intensity << " " << l.radius << " " << l.samples;
+        file << "\n";
+    }
+    const std::string text = file.str();
+    *needed = text.size() + 1;
+    if (!out || cap < *needed) return out ? RT_ERR_TOO_LARGE : RT_OK;
+    memcpy(out, text.c_str(), *needed);
+    return RT_OK;
+}
+
 }  // extern "C"

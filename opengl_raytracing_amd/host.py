@@ -32,7 +32,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
     "rt_count_rays", "rt_debug_stats", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
-    "rt_scene_parse", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_scene_parse", "rt_scene_write", "rt_strip_local_rows", "rt_deinterleave",
 ]
 
 RT_OK = 0
@@ -78,6 +78,7 @@ def load_library(build_if_missing=True):
     lib.rt_generate_aabb.argtypes = [vp, ci]
     lib.rt_camera_vectors.argtypes = [ctypes.c_float, ctypes.c_float, P(ctypes.c_float), P(ctypes.c_float), P(ctypes.c_float)]
     lib.rt_scene_parse.argtypes = [ctypes.c_char_p, vp, ci, P(ci), vp, ci, P(ci)]
+    lib.rt_scene_write.argtypes = [vp, ci, vp, ci, vp, vp, ctypes.c_char_p, ctypes.c_size_t, P(ctypes.c_size_t)]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     for name in EXPORTS:
@@ -120,6 +121,22 @@ def parse_scene(text, max_objects=512, max_lights=64):
     if rc:
         raise RtError(rc, "rt_scene_parse")
     return objs[: no.value].copy(), lts[: nl.value].copy()
+
+
+def write_scene(objects, lights):
+    """SceneIO::Save (/root/reference/src/SceneIO.h:124-142) -> text."""
+    lib = load_library()
+    objects = np.ascontiguousarray(objects)
+    lights = np.ascontiguousarray(lights)
+    need = ctypes.c_size_t(0)
+    rc = lib.rt_scene_write(_ptr(objects), len(objects), _ptr(lights), len(lights), None, None, None, 0, ctypes.byref(need))
+    if rc:
+        raise RtError(rc, "rt_scene_write")
+    buf = ctypes.create_string_buffer(need.value)
+    rc = lib.rt_scene_write(_ptr(objects), len(objects), _ptr(lights), len(lights), None, None, buf, need.value, ctypes.byref(need))
+    if rc:
+        raise RtError(rc, "rt_scene_write")
+    return buf.value.decode()
 
 
 def strip_local_rows(height, strip_rows, strip_count, strip_index):

@@ -149,6 +149,23 @@ def test_scene_parser_follows_sceneio(host):
     assert list(lts["shadowType"]) == [1, 1, 1] and list(lts["pcfSamples"]) == [4, 4, 4]
 
 
+def test_scene_writer_round_trip(host):
+    """SceneIO::Save format (SceneIO.h:50-73,124-142): parse(write(x)) reproduces every field the
+    format carries (6 significant digits, as ostream prints floats); the rest falls back to defaults."""
+    objs, lts = host.parse_scene(SCENE_TEXT)
+    text = host.write_scene(objs, lts)
+    lines = text.strip().splitlines()
+    assert len(lines) == 6 and lines[0].startswith("OBJECT SPHERE Object0 -2.5 0.5 -5 1 ")
+    assert lines[3].startswith("LIGHT DIRECTIONAL Light0 0 5 0 0.5 -1 -0.5 1 1 1 3 0 1")
+    assert all(len(l.split()) == 21 for l in lines[:3]) and all(len(l.split()) == 15 for l in lines[3:])
+    o2, l2 = host.parse_scene(text)
+    for fld in ("type", "position", "radius", "normal", "size", "mat_type", "albedo", "metallic", "roughness", "ior",
+                "transparency", "specular", "bounds_min", "bounds_max"):
+        np.testing.assert_allclose(o2[fld], objs[fld], rtol=1e-5, err_msg=fld)
+    for fld in ("type", "position", "direction", "color", "intensity", "radius", "samples"):
+        np.testing.assert_allclose(l2[fld], lts[fld], rtol=1e-5, err_msg=fld)
+
+
 @pytest.mark.reference
 def test_scene_parser_on_the_reference_scene_files(host):
     """The three shipped scenes (/root/reference/res/Scene) parse to the counts SURVEY.md lists."""
