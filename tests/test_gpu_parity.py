@@ -305,3 +305,32 @@ def test_fuzzed_scenes_bit_exact_vs_oracle(tracer, host, oracle, block):
         cpu = oracle.render(sc, p)
         assert_bit_exact(gpu, cpu, f"fuzz seed {seed}")
         assert tracer.count_rays(p) == cpu[3], f"fuzz seed {seed}: ray count"
+
+
+def test_cpp_host_example_matches_python_path(host, oracle, tmp_path):
+    """examples/host_swap.cpp drives the C ABI from plain C++ the way the reference's host would
+    (parse scene -> rt_set_scene -> rt_render -> rt_readback); its surface hashes must equal the
+    ctypes path's and the oracle's on the same scene."""
+    import json
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_swap")
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(repo, "include"), os.path.join(repo, "examples", "host_swap.cpp"),
+                    "-L", os.path.join(repo, "opengl_raytracing_amd"), "-lrt_mi355",
+                    "-Wl,-rpath," + os.path.join(repo, "opengl_raytracing_amd"), "-o", exe], check=True)
+    out = json.loads(subprocess.run([exe, "200", "120"], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    text = [l.split('"')[1].replace("\\n", "") for l in open(os.path.join(repo, "examples", "host_swap.cpp")) if l.strip().startswith('"OBJECT') or l.strip().startswith('"LIGHT')]
+    objs, lts = host.parse_scene("\n".join(text))
+    f, r, u = host.camera_vectors(-90.0, 0.0)
+    sc = scenes.Scene("cpp", objs, lts, 200, 120, 3, dict(cam_pos=(0.0, 1.0, 3.0), cam_dir=f, cam_up=u, cam_right=r, fov_deg=45.0))
+    col, pos, nrm, rays = oracle.render(sc, sc.params())
+
+    def fnv(a):
+        h = 1469598103934665603
+        for b in a.tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
+    assert out["rays"] == rays
+    assert out["color"] == fnv(col) and out["position"] == fnv(pos) and out["normal"] == fnv(nrm)
