@@ -167,7 +167,9 @@ int rt_count_rays(rt_context *ctx, const rt_params *p, uint64_t *rays);
 
 /* Kernel variant: 1 (default) = wavefront-packet kernel (packet culling, scalar-fed traversal),
  * 0 = exhaustive per-lane loop over all objects.  Both produce bit-identical surfaces; the switch
- * exists for A/B measurements and as a cross-check in the tests. */
+ * exists for A/B measurements and as a cross-check in the tests.  Adding 0x100
+ * disables the cost-feedback tile order of the packet kernel (frame k's measured tile costs give
+ * frame k+1's longest-first workgroup order; scheduling only, no pixel depends on it). */
 int rt_set_variant(rt_context *ctx, int variant);
 
 /* Diagnostics of the last rt_count_rays launch: out[0] rays, out[1] wave-level ray packets,

@@ -43,6 +43,13 @@ struct rt_context {
     unsigned long long *dRayCounter = nullptr;
     int variant = 1;   // 1 = wavefront-packet kernel (default), 0 = exhaustive per-lane loop
     unsigned long long lastStats[4] = {0, 0, 0, 0};   // rt_count_rays diagnostics (rt_debug_stats)
+    // cost-feedback tile scheduling state (packet kernel)
+    unsigned *dTileCost = nullptr, *dTileOrder = nullptr;
+    size_t capTiles = 0;
+    int fbTiles = 0, fbTilesX = 0, fbBt = 0;   // geometry the current order was measured on (0 = none)
+    hipStream_t fbStream = nullptr;
+    hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (stream switches wait on it)
+    bool feedback = true;
     std::string err;
 };
 
@@ -144,12 +151,48 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
     sc.compiled = c->dCompiled;
     sc.noise = c->dNoise;
     sc.sky = c->dSky;
+    sc.tileOrder = nullptr;
+    sc.tileCost = nullptr;
     if (!c->dCompiled) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene has not been called");
+    // Longest-first tile order from the previous frame's measured tile costs (same window geometry,
+    // same stream).  The first frame of a geometry runs in raster order and only records costs.
+    bool sortAfter = false;
+    int bt = 0, tile = 0, tilesX = 0, nTiles = 0;
+    if (c->variant == 1 && c->feedback && !counter && p->regionW > 0 && p->regionH > 0) {
+        rt_packet_geometry(c->nObj, p->regionW, p->regionH, &bt, &tile, &tilesX, &nTiles);
+        if ((size_t)nTiles > c->capTiles) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->fbStream) HIP_TRY(c, hipStreamSynchronize(c->fbStream));
+            if (c->dTileCost) HIP_TRY(c, hipFree(c->dTileCost));
+            if (c->dTileOrder) HIP_TRY(c, hipFree(c->dTileOrder));
+            c->dTileCost = c->dTileOrder = nullptr;
+            c->capTiles = 0;
+            c->fbTiles = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->dTileCost, (size_t)nTiles * sizeof(unsigned)));
+            HIP_TRY(c, hipMalloc((void **)&c->dTileOrder, (size_t)nTiles * sizeof(unsigned)));
+            c->capTiles = (size_t)nTiles;
+        }
+        if (c->fbStream && c->fbStream != s && c->evSort) HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
+        const bool same = c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt && c->fbStream == s;
+        if (!same) HIP_TRY(c, hipMemsetAsync(c->dTileCost, 0, (size_t)nTiles * sizeof(unsigned), s));
+        sc.tileOrder = same ? c->dTileOrder : nullptr;
+        sc.tileCost = c->dTileCost;
+        sortAfter = true;
+    }
     if (timed) HIP_TRY(c, hipEventRecord(c->evStart, s));
     HIP_TRY(c, rt_launch_render(f, sc, dColor, dPos, dNormal, counter, c->variant, s));
     if (timed) {
         HIP_TRY(c, hipEventRecord(c->evStop, s));
         c->timed = true;
+    }
+    if (sortAfter) {
+        HIP_TRY(c, rt_launch_lpt_sort(c->dTileCost, c->dTileOrder, nTiles, s));
+        if (!c->evSort) HIP_TRY(c, hipEventCreateWithFlags(&c->evSort, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->evSort, s));
+        c->fbTiles = nTiles;
+        c->fbTilesX = tilesX;
+        c->fbBt = bt;
+        c->fbStream = s;
     }
     return RT_OK;
 }
@@ -183,13 +226,15 @@ int rt_destroy(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter};
+    void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
+                    c->dTileCost, c->dTileOrder};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->evScene) (void)hipEventDestroy(c->evScene);
     if (c->evForeign) (void)hipEventDestroy(c->evForeign);
+    if (c->evSort) (void)hipEventDestroy(c->evSort);
     for (int k = 0; k < 2; k++) {
         if (c->evStage[k]) (void)hipEventDestroy(c->evStage[k]);
         if (c->hStage[k]) (void)hipHostFree(c->hStage[k]);
@@ -379,7 +424,10 @@ int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) {
 
 int rt_set_variant(rt_context *c, int variant) {
     if (!c) return RT_ERR_INVALID_ARG;
-    c->variant = variant;
+    // bit 8 (0x100) switches the cost-feedback tile order off (raster order every frame)
+    c->variant = variant & 0xff;
+    c->feedback = (variant & 0x100) == 0;
+    c->fbTiles = 0;
     return RT_OK;
 }
 

@@ -30,6 +30,11 @@ struct RtDeviceScene {
     const float4 *compiled;   // [nObj*RT_HOT_F4][nObj*RT_MAT_F4][nLt*RT_LGT_F4][halton2: 16][halton3: 16]
     const uint8_t *noise;     // R8 texels or nullptr
     const uint16_t *sky;      // 6*size*size*3 halfs or nullptr
+    // Cost-feedback tile scheduling (packet kernel): workgroup b renders tile tileOrder[b] (or b when
+    // null) and records its duration in tileCost[tile]; rt_launch_lpt_sort turns the costs of frame k
+    // into the longest-first order of frame k+1.  Pure scheduling: no pixel value depends on it.
+    const unsigned *tileOrder;
+    unsigned *tileCost;
 };
 
 static inline size_t rt_compiled_f4(int nObj, int nLt) {
@@ -41,5 +46,9 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
                                    float4 *dCompiled, hipStream_t s);
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
                             uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s);
+// Tile geometry of the packet kernel for a given scene size / window (so the ABI layer can size the
+// feedback buffers): workgroup threads, tile edge, tiles per row, total tiles.
+void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles);
+hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dOrder, int nTiles, hipStream_t s);
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
                                   int stripRows, int stripCount, size_t rankStrideBytes, hipStream_t s);

@@ -118,6 +118,7 @@ struct SceneLds {
     unsigned long long *stats = nullptr;   // diagnostic counters (instrumented build only)
     const float4 *global = nullptr;        // the same records in global memory (scalar-load path)
     float *park = nullptr;                 // per-thread LDS parking area, 9 floats x BLOCK_THREADS (packet kernel)
+    int tileX = 0, tileY = 0;              // this workgroup's tile (packet kernel; wave-uniform)
     int lgtF4Base = 0, haltonFloatBase = 0;   // offsets of the light / Halton sections (float4 / float units)
 };
 
@@ -702,8 +703,22 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     sc.haltonFloatBase = (sc.lgtF4Base + f.nLt * RT_LGT_F4) * 4;
     sc.park = (float *)(lds + nF4 + 1);      // after the scene and the 16-byte counter slot
 
+    // tile of this workgroup: longest-first order from the previous frame's measured costs, if any
+    constexpr int TILE_ = (BT == 256) ? 16 : 8;
+    const int tilesX = (f.p.regionW + TILE_ - 1) / TILE_;
+    const unsigned tile = dsc.tileOrder ? dsc.tileOrder[blockIdx.x] : blockIdx.x;
+    sc.tileX = (int)(tile % (unsigned)tilesX);
+    sc.tileY = (int)(tile / (unsigned)tilesX);
+    const long long t0 = clock64();
+
     unsigned rays = 0;
     render_packet<COUNT, BT>(f, dsc, sc, gColor, gPosition, gNormal, rays);
+
+    if (dsc.tileCost && (threadIdx.x & 63) == 0) {     // one add per wave: tile cost = sum of its waves' cycles / 64
+        const unsigned c = (unsigned)(((unsigned long long)(clock64() - t0)) >> 6);
+        if (BT == 64) dsc.tileCost[tile] = c;
+        else atomicAdd(&dsc.tileCost[tile], c);
+    }
 
     if (COUNT) {
         unsigned long long *blockRays = (unsigned long long *)(lds + nF4);
@@ -745,9 +760,10 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
     if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
     const size_t sceneBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
     if (variant == 1) {
-        const bool small = f.nObj <= RT_PK_SMALL_SCENE;
-        const int bt = small ? 64 : 256, tile = small ? 8 : 16;
-        dim3 grid((f.p.regionW + tile - 1) / tile, (f.p.regionH + tile - 1) / tile);
+        int bt, tile, tilesX, nTiles;
+        rt_packet_geometry(f.nObj, f.p.regionW, f.p.regionH, &bt, &tile, &tilesX, &nTiles);
+        const bool small = bt == 64;
+        dim3 grid(nTiles);
         const size_t ldsBytes = sceneBytes + 9 * bt * sizeof(float);                    // + the parking area
         if (small) {
             if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
@@ -763,6 +779,50 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
         else
             hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
     }
+    return hipGetLastError();
+}
+
+void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles) {
+    const bool small = nObj <= RT_PK_SMALL_SCENE;
+    *bt = small ? 64 : 256;
+    *tile = small ? 8 : 16;
+    *tilesX = (regionW + *tile - 1) / *tile;
+    *nTiles = *tilesX * ((regionH + *tile - 1) / *tile);
+}
+
+// Longest-processing-time-first order from measured tile costs: 256 linear cost bins (descending),
+// counting sort by one 1024-thread workgroup (a frame has at most a few 1e5 tiles).  Order inside a
+// bin is arbitrary -- this is a scheduling hint, never a data dependency.  Costs are cleared for the
+// next frame's accumulation.
+__global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict__ cost, unsigned *__restrict__ order, int nTiles) {
+    __shared__ unsigned bins[256];
+    __shared__ unsigned maxCost;
+    if (threadIdx.x < 256) bins[threadIdx.x] = 0;
+    if (threadIdx.x == 0) maxCost = 1;
+    __syncthreads();
+    unsigned mx = 1;
+    for (int i = threadIdx.x; i < nTiles; i += 1024) mx = max(mx, cost[i]);
+    atomicMax(&maxCost, mx);
+    __syncthreads();
+    const float scale = 255.0f / (float)maxCost;
+    for (int i = threadIdx.x; i < nTiles; i += 1024) atomicAdd(&bins[255 - min(255, (int)((float)cost[i] * scale))], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int b = 0; b < 256; b++) { unsigned n = bins[b]; bins[b] = run; run += n; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nTiles; i += 1024) {
+        const unsigned pos = atomicAdd(&bins[255 - min(255, (int)((float)cost[i] * scale))], 1u);
+        order[pos] = (unsigned)i;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nTiles; i += 1024) cost[i] = 0;
+}
+
+hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dOrder, int nTiles, hipStream_t s) {
+    if (nTiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_lpt_sort_kernel, dim3(1), dim3(1024), 0, s, dCost, dOrder, nTiles);
     return hipGetLastError();
 }
 
