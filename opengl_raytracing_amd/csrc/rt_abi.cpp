@@ -47,6 +47,7 @@ struct rt_context {
     unsigned *dTileCost = nullptr, *dTileOrder = nullptr;
     size_t capTiles = 0;
     int fbTiles = 0, fbTilesX = 0, fbBt = 0;   // geometry the current order was measured on (0 = none)
+    unsigned fbAge = 0;                        // frames since that geometry was first seen
     hipStream_t fbStream = nullptr;
     hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (stream switches wait on it)
     bool feedback = true;
@@ -186,9 +187,16 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         c->timed = true;
     }
     if (sortAfter) {
-        HIP_TRY(c, rt_launch_lpt_sort(c->dTileCost, c->dTileOrder, nTiles, s));
-        if (!c->evSort) HIP_TRY(c, hipEventCreateWithFlags(&c->evSort, hipEventDisableTiming));
-        HIP_TRY(c, hipEventRecord(c->evSort, s));
+        // Tile costs drift slowly from frame to frame: re-sort on the first two frames of a geometry,
+        // then every 8th (costs keep accumulating in between, which only smooths the estimate).
+        const bool fresh = !(c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt && c->fbStream == s);
+        if (fresh) c->fbAge = 0;
+        if (c->fbAge < 2 || (c->fbAge & 7u) == 0) {
+            HIP_TRY(c, rt_launch_lpt_sort(c->dTileCost, c->dTileOrder, nTiles, s));
+            if (!c->evSort) HIP_TRY(c, hipEventCreateWithFlags(&c->evSort, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->evSort, s));
+        }
+        c->fbAge++;
         c->fbTiles = nTiles;
         c->fbTilesX = tilesX;
         c->fbBt = bt;
