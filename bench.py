@@ -224,6 +224,12 @@ def main():
             except Exception:
                 traffic = None
         compulsory = (my_px * 40 + len(sc.objects) * 176 + len(sc.lights) * 96) / (kernel_ms * 1e-3) / 1e9
+        # secondary, honest limiter: algorithmic flops of the exhaustive traversal
+        #   F_alg = R*(nObj*25 + 40) + S*nLt*120,  S = shading points ~ R / (1 + sum_l s_l)
+        rays_per_shade = 1 + sum((int(l["pcfSamples"]) if int(l["shadowType"]) == 1 else
+                                  16 + int(l["pcfSamples"]) if int(l["shadowType"]) == 2 else 0) for l in sc.lights)
+        f_alg = my_rays * (len(sc.objects) * 25 + 40) + (my_rays / rays_per_shade) * len(sc.lights) * 120
+        valu_tflops = f_alg / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "Mray/s", "value": round(value, 1), "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -245,6 +251,10 @@ def main():
                          "note": "algorithmic bytes = rays*nObj*176 + px*40 + scene (SURVEY.md 8(d)); the stream is "
                                  "served from LDS, so achieved may exceed the HBM peak -- it is not physical bandwidth",
                          "compulsory_only_GBps": round(compulsory, 1)},
+            "roofline_valu": {"bound": "fp32 valu", "achieved": round(valu_tflops, 1), "peak": FP32_VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(valu_tflops / FP32_VALU_PEAK_TFLOPS, 3),
+                              "note": "algorithmic flops of the exhaustive traversal (SURVEY.md 8(d)); packet culling "
+                                      "skips most of them, so this is work-equivalent throughput"},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as O   # checker / reported baseline only
