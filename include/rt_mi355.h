@@ -198,6 +198,19 @@ int rt_scene_write(const void *objects, int nObj, const void *lights, int nLt,
                    const char *const *objNames, const char *const *lightNames, char *out,
                    size_t cap, size_t *needed);
 
+/* ---- next row after the ray tracer: the TAA resolve pass
+ *      (/root/reference/shader/taaFs.glsl:13-53; host side ForwardShadingPipeline.cpp:231-260).
+ *      dCurrent = gColor of this frame (rgba32f, sampled LINEAR/REPEAT), dHistory = the previous
+ *      resolve (rgba32f, LINEAR/CLAMP_TO_EDGE), dNormal = gNormal (rgba16f, NEAREST/REPEAT), all
+ *      width x height device surfaces as produced by rt_render; dOut = the new history (rgba32f).
+ *      The caller ping-pongs dHistory/dOut like historyTex[2] (:233, :248).  Asynchronous on
+ *      hipStream (NULL = the context's stream). */
+int rt_taa_resolve(rt_context *ctx, const void *dCurrent, const void *dHistory, const void *dNormal,
+                   void *dOut, int width, int height, float blendFactor, float jitterX,
+                   float jitterY, void *hipStream);
+/* uJitterX / uJitterY of ForwardShadingPipeline.cpp:241-242 (global.cpp:41-51's haltonSequence). */
+int rt_taa_jitter(int frameCount, int width, int height, float *jitterX, float *jitterY);
+
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "librt_mi355.so")
 ORACLE_DIR = os.path.join(REPO, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle_rt.so")
 
-SOURCES = ["rt_kernels.hip", "rt_abi.cpp", "rt_host.cpp"]
+SOURCES = ["rt_kernels.hip", "rt_post.hip", "rt_abi.cpp", "rt_host.cpp"]
 HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_packet.inc"), os.path.join(REPO, "include", "rt_mi355.h")]
 
 # -ffp-contract=off: the reference's GL never fuses a*b+c; IEEE divide and
@@ -57,7 +57,7 @@ def build_library(force=False, verbose=True, extra_flags=(), out=None):
 def build_oracle(force=False, verbose=True):
     """gcc build of the CPU restatement (+ the llvmpipe harness when Mesa headers exist).
     Building the checker is not using it."""
-    deps = [os.path.join(ORACLE_DIR, f) for f in ("rt_oracle.c", "rt_oracle.h", "Makefile")]
+    deps = [os.path.join(ORACLE_DIR, f) for f in ("rt_oracle.c", "rt_post_oracle.c", "rt_oracle.h", "Makefile")]
     if force or _stale(ORACLE_LIB, deps):
         if verbose:
             print("[build] make -C oracle", flush=True)

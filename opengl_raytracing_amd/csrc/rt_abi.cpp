@@ -445,6 +445,18 @@ int rt_debug_stats(rt_context *c, uint64_t out[4]) {
     return RT_OK;
 }
 
+int rt_taa_resolve(rt_context *c, const void *dCurrent, const void *dHistory, const void *dNormal, void *dOut, int width,
+                   int height, float blendFactor, float jitterX, float jitterY, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!dCurrent || !dHistory || !dNormal || !dOut || width <= 0 || height <= 0)
+        return fail(c, RT_ERR_INVALID_ARG, "bad rt_taa_resolve arguments");
+    if (dOut == dCurrent || dOut == dHistory) return fail(c, RT_ERR_INVALID_ARG, "rt_taa_resolve cannot run in place");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    HIP_TRY(c, rt_launch_taa_resolve(dCurrent, dHistory, dNormal, dOut, width, height, blendFactor, jitterX, jitterY, s));
+    return RT_OK;
+}
+
 const char *rt_last_error(rt_context *c) { return c ? c->err.c_str() : "NULL context"; }
 
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex) {

@@ -50,5 +50,7 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
 // feedback buffers): workgroup threads, tile edge, tiles per row, total tiles.
 void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles);
 hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dOrder, int nTiles, hipStream_t s);
+hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
+                                 float blend, float jx, float jy, hipStream_t s);
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
                                   int stripRows, int stripCount, size_t rankStrideBytes, hipStream_t s);

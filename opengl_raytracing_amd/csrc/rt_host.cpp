@@ -182,4 +182,18 @@ int rt_scene_write(const void *objects, int nObj, const void *lights, int nLt, c
     return RT_OK;
 }
 
+int rt_taa_jitter(int frameCount, int width, int height, float *jitterX, float *jitterY) {
+    if (!jitterX || !jitterY || width <= 0 || height <= 0) return RT_ERR_INVALID_ARG;
+    // haltonSequence of /root/reference/src/global.cpp:41-51 (note its floor(i / base) on ints)
+    auto halton = [](int index, int base) {
+        float result = 0.0f, f = 1.0f / (float)base;
+        int i = index;
+        while (i > 0) { result += f * (float)(i % base); i = (int)floorf((float)(i / base)); f /= (float)base; }
+        return result;
+    };
+    *jitterX = halton(frameCount % 8, 2) * 0.5f / (float)width;    // ForwardShadingPipeline.cpp:241
+    *jitterY = halton(frameCount % 8, 3) * 0.5f / (float)height;   // :242
+    return RT_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,126 @@
+// rt_post.hip -- post passes that consume the ray tracer's surfaces, as gfx950 HIP kernels.
+// First (and so far only) one: the TAA resolve of /root/reference/shader/taaFs.glsl:13-53, driven
+// like /root/reference/src/ForwardShadingPipeline.cpp:231-260.  Unlike the ray tracer this IS a
+// bandwidth-bound kernel: 56 B of compulsory HBM traffic per pixel (current 16 + history 16 +
+// gNormal 8 read, 16 written) against ~150 flops.
+//
+// Layout: 256-thread workgroup = 32x8 pixels; the current frame's 34x10 tile (1-texel halo, the
+// 3x3 neighbourhood clamp and the jittered bilinear tap both live in it) is staged once in LDS with
+// coalesced 16-B loads; history (4 taps, normally collapsing onto one texel) and the two gNormal
+// taps come straight from L1/L2.  One float4 store per lane.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr int TX = 32, TY = 8, HALO = 1, LW = TX + 2 * HALO, LH = TY + 2 * HALO;
+
+__device__ __forceinline__ int wrapi(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
+__device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); }
+
+struct rgb { float x, y, z; };
+__device__ __forceinline__ rgb lerp3(rgb a, rgb b, float w) {   // a + w*(b-a), per llvmpipe's float path
+    rgb r; r.x = a.x + w * (b.x - a.x); r.y = a.y + w * (b.y - a.y); r.z = a.z + w * (b.z - a.z); return r;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void rt_taa_resolve_kernel(const float4 *__restrict__ current,
+                                                             const float4 *__restrict__ history,
+                                                             const uint2 *__restrict__ normal,   // half4 per pixel
+                                                             float4 *__restrict__ out, int W, int H, float blendFactor,
+                                                             float jitterX, float jitterY) {
+    __shared__ float4 tile[LH][LW];
+    const int bx = blockIdx.x * TX, by = blockIdx.y * TY;
+    // stage the current-frame tile; texels outside the image are stored with REPEAT addressing (what the
+    // bilinear tap needs); the 3x3 clamp below substitutes 0 for them itself (texelFetch out of range)
+    for (int k = threadIdx.x; k < LW * LH; k += 256) {
+        const int lx = k % LW, ly = k / LW;
+        const int gx = wrapi(bx + lx - HALO, W), gy = wrapi(by + ly - HALO, H);
+        tile[ly][lx] = current[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = bx + tx, j = by + ty;
+    if (i >= W || j >= H) return;
+
+    auto cur_at = [&](int x, int y) -> rgb {   // REPEAT-addressed current texel (x, y may be any integer)
+        const int lx = x - bx + HALO, ly = y - by + HALO;
+        float4 q;
+        if (lx >= 0 && lx < LW && ly >= 0 && ly < LH) q = tile[ly][lx];
+        else q = current[(size_t)wrapi(y, H) * W + wrapi(x, W)];
+        rgb r; r.x = q.x; r.y = q.y; r.z = q.z; return r;
+    };
+
+    const float u = ((float)i + 0.5f) / (float)W, v = ((float)j + 0.5f) / (float)H;   // TexCoords
+    const float ju = u + jitterX, jv = v + jitterY;                                     // taaFs.glsl:23
+    // current = texture(uCurrentFrame, jitteredUV): LINEAR, REPEAT                     :24
+    rgb cur;
+    {
+        const float x = ju * (float)W - 0.5f, y = jv * (float)H - 0.5f;
+        const float fx = floorf(x), fy = floorf(y);
+        const float wx = x - fx, wy = y - fy;
+        const int x0 = (int)fx, y0 = (int)fy;
+        rgb a = lerp3(cur_at(x0, y0), cur_at(x0 + 1, y0), wx);
+        rgb b = lerp3(cur_at(x0, y0 + 1), cur_at(x0 + 1, y0 + 1), wx);
+        cur = lerp3(a, b, wy);
+    }
+    // history = texture(uHistory, TexCoords): LINEAR, CLAMP_TO_EDGE                   :27
+    rgb his;
+    {
+        const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+        const float fx = floorf(x), fy = floorf(y);
+        const float wx = x - fx, wy = y - fy;
+        const int x0 = clampi((int)fx, W), x1 = clampi((int)fx + 1, W), y0 = clampi((int)fy, H), y1 = clampi((int)fy + 1, H);
+        auto h_at = [&](int xx, int yy) -> rgb { float4 q = history[(size_t)yy * W + xx]; rgb r; r.x = q.x; r.y = q.y; r.z = q.z; return r; };
+        rgb a = lerp3(h_at(x0, y0), h_at(x1, y0), wx);
+        rgb b = lerp3(h_at(x0, y1), h_at(x1, y1), wx);
+        his = lerp3(a, b, wy);
+    }
+    // neighbourhood colour box, texelFetch (0 outside the image)                       :30-37
+    rgb mn = cur, mx = cur;
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int x = i + dx, y = j + dy;
+            const bool inb = x >= 0 && y >= 0 && x < W && y < H;
+            const float4 q = tile[ty + dy + HALO][tx + dx + HALO];
+            const float nx = inb ? q.x : 0.0f, ny = inb ? q.y : 0.0f, nz = inb ? q.z : 0.0f;
+            mn.x = fminf(mn.x, nx); mn.y = fminf(mn.y, ny); mn.z = fminf(mn.z, nz);
+            mx.x = fmaxf(mx.x, nx); mx.y = fmaxf(mx.y, ny); mx.z = fmaxf(mx.z, nz);
+        }
+    }
+    // normal check, NEAREST / REPEAT                                                   :40-45
+    float bf = 0.0f;
+    {
+        const int px = wrapi((int)floorf(u * (float)W), W), py = wrapi((int)floorf(v * (float)H), H);
+        const int cx = wrapi((int)floorf(ju * (float)W), W), cy = wrapi((int)floorf(jv * (float)H), H);
+        const uint2 pn = normal[(size_t)py * W + px], cn = normal[(size_t)cy * W + cx];
+        const float pnx = __half2float(__ushort_as_half((unsigned short)(pn.x & 0xffffu))), pny = __half2float(__ushort_as_half((unsigned short)(pn.x >> 16)));
+        const float pnz = __half2float(__ushort_as_half((unsigned short)(pn.y & 0xffffu)));
+        const float cnx = __half2float(__ushort_as_half((unsigned short)(cn.x & 0xffffu))), cny = __half2float(__ushort_as_half((unsigned short)(cn.x >> 16)));
+        const float cnz = __half2float(__ushort_as_half((unsigned short)(cn.y & 0xffffu)));
+        const float d = (pnz * cnz + pny * cny) + pnx * cnx;
+        if (d < 0.9f) bf = blendFactor * 0.2f;
+    }
+    // clipAABB (:13-19) then mix(history, current, blendFactor) (:51)
+    auto resolve = [&](float h, float c, float lo, float hi) -> float {
+        const float center = 0.5f * (hi + lo), extents = 0.5f * (hi - lo);
+        float clip = h - center;
+        clip = fminf(fmaxf(clip, -extents), extents);
+        const float hc = center + clip;
+        return hc + bf * (c - hc);
+    };
+    out[(size_t)j * W + i] = make_float4(resolve(his.x, cur.x, mn.x, mx.x), resolve(his.y, cur.y, mn.y, mx.y),
+                                         resolve(his.z, cur.z, mn.z, mx.z), 1.0f);
+}
+
+hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
+                                 float blend, float jx, float jy, hipStream_t s) {
+    dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY);
+    hipLaunchKernelGGL(rt_taa_resolve_kernel, grid, dim3(256), 0, s, (const float4 *)current, (const float4 *)history,
+                       (const uint2 *)normal, (float4 *)out, W, H, blend, jx, jy);
+    return hipGetLastError();
+}

@@ -32,7 +32,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
     "rt_count_rays", "rt_debug_stats", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
-    "rt_scene_parse", "rt_scene_write", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_strip_local_rows", "rt_deinterleave",
 ]
 
 RT_OK = 0
@@ -79,6 +79,9 @@ def load_library(build_if_missing=True):
     lib.rt_camera_vectors.argtypes = [ctypes.c_float, ctypes.c_float, P(ctypes.c_float), P(ctypes.c_float), P(ctypes.c_float)]
     lib.rt_scene_parse.argtypes = [ctypes.c_char_p, vp, ci, P(ci), vp, ci, P(ci)]
     lib.rt_scene_write.argtypes = [vp, ci, vp, ci, vp, vp, ctypes.c_char_p, ctypes.c_size_t, P(ctypes.c_size_t)]
+    cf = ctypes.c_float
+    lib.rt_taa_resolve.argtypes = [vp, vp, vp, vp, vp, ci, ci, cf, cf, cf, vp]
+    lib.rt_taa_jitter.argtypes = [ci, ci, ci, P(cf), P(cf)]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     for name in EXPORTS:
@@ -137,6 +140,15 @@ def write_scene(objects, lights):
     if rc:
         raise RtError(rc, "rt_scene_write")
     return buf.value.decode()
+
+
+def taa_jitter(frame_count, width, height):
+    """uJitterX/uJitterY of /root/reference/src/ForwardShadingPipeline.cpp:241-242."""
+    jx, jy = ctypes.c_float(), ctypes.c_float()
+    rc = load_library().rt_taa_jitter(frame_count, width, height, ctypes.byref(jx), ctypes.byref(jy))
+    if rc:
+        raise RtError(rc, "rt_taa_jitter")
+    return jx.value, jy.value
 
 
 def strip_local_rows(height, strip_rows, strip_count, strip_index):
@@ -243,6 +255,12 @@ class RayTracer:
         n = ctypes.c_uint64()
         self._check(self.lib.rt_count_rays(self.ctx, ctypes.byref(params), ctypes.byref(n)), "rt_count_rays")
         return n.value
+
+    def taa_resolve(self, d_current, d_history, d_normal, d_out, width, height, blend, jx, jy, stream=None):
+        """TAA resolve pass on device surfaces (raw device pointers as ints)."""
+        self._check(self.lib.rt_taa_resolve(self.ctx, ctypes.c_void_p(d_current), ctypes.c_void_p(d_history),
+                                            ctypes.c_void_p(d_normal), ctypes.c_void_p(d_out), width, height, blend, jx, jy,
+                                            ctypes.c_void_p(stream) if stream else None), "rt_taa_resolve")
 
     def debug_stats(self):
         out = (ctypes.c_uint64 * 4)()

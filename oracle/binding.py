@@ -35,6 +35,11 @@ def load():
         lib.orc_halton.argtypes = [vp, vp, vp, ci]
         lib.orc_float_to_half_rtz.argtypes = [vp, vp, ci]
         lib.orc_sample_cube.argtypes = [vp, ci, vp, vp, ci]
+        cf = ctypes.c_float
+        lib.orc_taa_resolve.argtypes = [vp, vp, vp, ci, ci, cf, cf, cf, vp]
+        lib.orc_taa_resolve.restype = None
+        lib.orc_taa_jitter.argtypes = [ci, ci, ci, ctypes.POINTER(cf), ctypes.POINTER(cf)]
+        lib.orc_taa_jitter.restype = None
         _LIB = lib
     return _LIB
 
@@ -92,6 +97,23 @@ def sample_cube(sky, dirs):
     out = np.zeros_like(dirs)
     load().orc_sample_cube(_ptr(sky), sky.shape[1], _ptr(dirs), _ptr(out), len(dirs))
     return out
+
+
+def taa_resolve(current, history, normal, blend, jx, jy):
+    """CPU restatement of taaFs.glsl.  current/history f32[h,w,4], normal f16|f32[h,w,4] -> f32[h,w,4]."""
+    current = np.ascontiguousarray(current, dtype=np.float32)
+    history = np.ascontiguousarray(history, dtype=np.float32)
+    normal = np.ascontiguousarray(normal.astype(np.float32))
+    h, w = current.shape[:2]
+    out = np.zeros((h, w, 4), dtype=np.float32)
+    load().orc_taa_resolve(_ptr(current), _ptr(history), _ptr(normal), w, h, blend, jx, jy, _ptr(out))
+    return out
+
+
+def taa_jitter(frame_count, w, h):
+    jx, jy = ctypes.c_float(), ctypes.c_float()
+    load().orc_taa_jitter(frame_count, w, h, ctypes.byref(jx), ctypes.byref(jy))
+    return jx.value, jy.value
 
 
 # ---- the reference shader itself on Mesa llvmpipe ------------------------------------------
@@ -153,3 +175,32 @@ def run_probe(glsl_text, in_array, out_dtype, out_count, groups):
         nbytes = int(np.dtype(out_dtype).itemsize * out_count)
         subprocess.run([HARNESS, "probe", g, i, o, str(nbytes), str(groups)], check=True, capture_output=True)
         return np.fromfile(o, dtype=out_dtype)
+
+
+def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=False):
+    """One full-screen fragment pass of the reference (gl_harness postfx).
+    textures: list of (sampler_name, float32 array [h,w,4], dict(half=False, linear=False, clamp=False));
+    uniforms: list of (name, value) with value int | float | tuple.  -> float32 [out_h, out_w, 4]."""
+    if not (os.path.exists(HARNESS) and os.path.exists(vs_path) and os.path.exists(fs_path)):
+        raise RuntimeError("gl_harness or the reference shaders are not available here")
+    with tempfile.TemporaryDirectory(prefix="rtpfx_") as d:
+        job, out = os.path.join(d, "job.bin"), os.path.join(d, "out.f32")
+        with open(job, "wb") as f:
+            f.write(b"PFXJOB1\0")
+            f.write(struct.pack("<5i", out_w, out_h, int(out_half), len(textures), len(uniforms)))
+            for name, arr, opt in textures:
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                h, w = arr.shape[:2]
+                f.write(struct.pack("<32s5i", name.encode(), w, h, int(opt.get("half", False)), int(opt.get("linear", False)),
+                                    int(opt.get("clamp", False))))
+                f.write(arr.tobytes())
+            for name, val in uniforms:
+                if isinstance(val, (bool, int, np.integer)):
+                    f.write(struct.pack("<32sii3f", name.encode(), 0, int(val), 0.0, 0.0, 0.0))
+                elif isinstance(val, (float, np.floating)):
+                    f.write(struct.pack("<32si4f", name.encode(), 1, float(val), 0.0, 0.0, 0.0))
+                else:
+                    v = list(val) + [0.0] * (4 - len(val))
+                    f.write(struct.pack("<32si4f", name.encode(), 2 if len(val) == 2 else 4, *v))
+        subprocess.run([HARNESS, "postfx", vs_path, fs_path, job, out], check=True, capture_output=True)
+        return np.fromfile(out, dtype=np.float32).reshape(out_h, out_w, 4)

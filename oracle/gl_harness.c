@@ -20,6 +20,9 @@
  *        job.bin = "RTJOB1" file written by tests/golden/make_golden.py (layout below).
  *        Writes <out_prefix>.color.f32 / .pos.f32 / .normal.f32  (W*H*4 float each,
  *        row 0 = bottom row, GL origin) and prints one JSON line with timings.
+ *   gl_harness postfx <vs.glsl> <fs.glsl> <job.bin> <out.f32>
+ *        one full-screen-quad fragment pass into an FBO (the reference's post passes: TAA, bloom);
+ *        see mode_postfx for the job layout.
  *   gl_harness probe  <probe.glsl> <in.bin> <out.bin> <out_bytes> <groups_x>
  *        micro-kernel mode: SSBO binding 0 = in.bin, SSBO binding 1 = out (zeroed),
  *        glDispatchCompute(groups_x,1,1).  Used to pin llvmpipe's lowering of
@@ -99,6 +102,18 @@ GLF(void, glDispatchCompute, GLuint, GLuint, GLuint);
 GLF(void, glMemoryBarrier, GLbitfield);
 GLF(void, glFinish, void);
 GLF(void, glGetTexImage, GLenum, GLint, GLenum, GLenum, void *);
+GLF(void, glGenVertexArrays, GLsizei, GLuint *);
+GLF(void, glBindVertexArray, GLuint);
+GLF(void, glVertexAttribPointer, GLuint, GLint, GLenum, GLboolean, GLsizei, const void *);
+GLF(void, glEnableVertexAttribArray, GLuint);
+GLF(void, glGenFramebuffers, GLsizei, GLuint *);
+GLF(void, glBindFramebuffer, GLenum, GLuint);
+GLF(void, glFramebufferTexture2D, GLenum, GLenum, GLenum, GLuint, GLint);
+GLF(GLenum, glCheckFramebufferStatus, GLenum);
+GLF(void, glViewport, GLint, GLint, GLsizei, GLsizei);
+GLF(void, glDrawArrays, GLenum, GLint, GLsizei);
+GLF(void, glClear, GLbitfield);
+GLF(void, glUniform4f, GLint, GLfloat, GLfloat, GLfloat, GLfloat);
 
 #define LOAD(name)                                             \
     do {                                                       \
@@ -120,6 +135,9 @@ static void load_gl(void) {
     LOAD(glBindImageTexture); LOAD(glGenBuffers); LOAD(glBindBuffer); LOAD(glBufferData);
     LOAD(glBindBufferBase); LOAD(glGetBufferSubData); LOAD(glDispatchCompute);
     LOAD(glMemoryBarrier); LOAD(glFinish); LOAD(glGetTexImage);
+    LOAD(glGenVertexArrays); LOAD(glBindVertexArray); LOAD(glVertexAttribPointer); LOAD(glEnableVertexAttribArray);
+    LOAD(glGenFramebuffers); LOAD(glBindFramebuffer); LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus);
+    LOAD(glViewport); LOAD(glDrawArrays); LOAD(glClear); LOAD(glUniform4f);
 }
 
 static void gl_check(const char *where) {
@@ -242,9 +260,8 @@ static char *patch_depth(const char *src, int depth) {
     return out;
 }
 
-static GLuint build_program(const char *src, double *compile_s) {
-    double t0 = now_s();
-    GLuint sh = p_glCreateShader(GL_COMPUTE_SHADER);
+static GLuint compile_stage(GLenum kind, const char *src) {
+    GLuint sh = p_glCreateShader(kind);
     p_glShaderSource(sh, 1, &src, NULL);
     p_glCompileShader(sh);
     GLint ok = 0;
@@ -255,6 +272,13 @@ static GLuint build_program(const char *src, double *compile_s) {
         fprintf(stderr, "compile failed:\n%s\n", log);
         exit(4);
     }
+    return sh;
+}
+
+static GLuint build_program(const char *src, double *compile_s) {
+    double t0 = now_s();
+    GLuint sh = compile_stage(GL_COMPUTE_SHADER, src);
+    GLint ok = 0;
     GLuint prog = p_glCreateProgram();
     p_glAttachShader(prog, sh);
     p_glLinkProgram(prog);
@@ -462,10 +486,106 @@ static int mode_probe(int argc, char **argv) {
     return write_file(argv[4], zero, outlen) ? 5 : 0;
 }
 
+/* ------------------------------------------------------------------ postfx mode */
+/* Full-screen-quad fragment pass, the way the reference runs its post passes
+ * (/root/reference/src/global.cpp:13-39 RenderQuad + an FBO with one colour attachment):
+ *   gl_harness postfx <vs.glsl> <fs.glsl> <job.bin> <out.f32>
+ * job.bin ("PFXJOB1"): int32 outW, outH, outFmt (0 rgba32f, 1 rgba16f), nTex, nUni; then per texture
+ *   char name[32]; int32 w, h, fmt, filter (0 nearest, 1 linear), wrap (0 repeat, 1 clamp_to_edge); w*h*4 floats;
+ * then per uniform  char name[32]; int32 kind (0 int, 1 float, 2 vec2, 4 vec4); float v[4] (ints as float bits).
+ * Texture k is bound to unit k and its sampler uniform `name` set to k.  Writes outW*outH*4 floats. */
+typedef struct { char name[32]; int32_t w, h, fmt, filter, wrap; } PfxTex;
+typedef struct { char name[32]; int32_t kind; float v[4]; } PfxUni;
+
+static int mode_postfx(int argc, char **argv) {
+    if (argc < 6) { fprintf(stderr, "usage: postfx <vs> <fs> <job.bin> <out.f32>\n"); return 2; }
+    char *vs = read_file(argv[2], NULL), *fs = read_file(argv[3], NULL);
+    if (!vs || !fs) return EXIT_SKIP;
+    size_t joblen = 0;
+    char *job = read_file(argv[4], &joblen);
+    if (!job || joblen < 28 || memcmp(job, "PFXJOB1", 7)) { fprintf(stderr, "bad job\n"); return 2; }
+    int32_t hd[5];
+    memcpy(hd, job + 8, sizeof hd);
+    const int outW = hd[0], outH = hd[1], outFmt = hd[2], nTex = hd[3], nUni = hd[4];
+    if (bootstrap_gl()) { fprintf(stderr, "Mesa swrast unavailable\n"); return EXIT_SKIP; }
+    GLuint prog = p_glCreateProgram();
+    p_glAttachShader(prog, compile_stage(GL_VERTEX_SHADER, vs));
+    p_glAttachShader(prog, compile_stage(GL_FRAGMENT_SHADER, fs));
+    p_glLinkProgram(prog);
+    GLint ok = 0;
+    p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (!ok) { char log[4096]; p_glGetProgramInfoLog(prog, sizeof log, NULL, log); fprintf(stderr, "link failed:\n%s\n", log); return 4; }
+    p_glUseProgram(prog);
+    const char *q = job + 8 + sizeof hd;
+    for (int k = 0; k < nTex; k++) {
+        PfxTex t;
+        memcpy(&t, q, sizeof t); q += sizeof t;
+        GLuint tex;
+        p_glGenTextures(1, &tex);
+        p_glActiveTexture(GL_TEXTURE0 + k);
+        p_glBindTexture(GL_TEXTURE_2D, tex);
+        p_glTexImage2D(GL_TEXTURE_2D, 0, t.fmt ? GL_RGBA16F : GL_RGBA32F, t.w, t.h, 0, GL_RGBA, GL_FLOAT, q);
+        q += (size_t)t.w * t.h * 16;
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, t.filter ? GL_LINEAR : GL_NEAREST);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, t.filter ? GL_LINEAR : GL_NEAREST);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, t.wrap ? GL_CLAMP_TO_EDGE : GL_REPEAT);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, t.wrap ? GL_CLAMP_TO_EDGE : GL_REPEAT);
+        p_glUniform1i(p_glGetUniformLocation(prog, t.name), k);
+    }
+    for (int k = 0; k < nUni; k++) {
+        PfxUni u;
+        memcpy(&u, q, sizeof u); q += sizeof u;
+        GLint loc = p_glGetUniformLocation(prog, u.name);
+        int32_t iv; memcpy(&iv, &u.v[0], 4);
+        if (u.kind == 0) p_glUniform1i(loc, iv);
+        else if (u.kind == 1) p_glUniform1f(loc, u.v[0]);
+        else if (u.kind == 2) p_glUniform2f(loc, u.v[0], u.v[1]);
+        else p_glUniform4f(loc, u.v[0], u.v[1], u.v[2], u.v[3]);
+    }
+    gl_check("postfx inputs");
+    GLuint outTex, fbo, vao, vbo;
+    p_glGenTextures(1, &outTex);
+    p_glActiveTexture(GL_TEXTURE0 + nTex);
+    p_glBindTexture(GL_TEXTURE_2D, outTex);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, outFmt ? GL_RGBA16F : GL_RGBA32F, outW, outH, 0, GL_RGBA, GL_FLOAT, NULL);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    p_glGenFramebuffers(1, &fbo);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, outTex, 0);
+    if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) { fprintf(stderr, "FBO incomplete\n"); return 3; }
+    p_glViewport(0, 0, outW, outH);
+    static const float quad[] = { /* global.cpp:16-24: position.xy, texcoord.xy */
+        -1.0f, 1.0f, 0.0f, 1.0f,  -1.0f, -1.0f, 0.0f, 0.0f,  1.0f, -1.0f, 1.0f, 0.0f,
+        -1.0f, 1.0f, 0.0f, 1.0f,   1.0f, -1.0f, 1.0f, 0.0f,  1.0f,  1.0f, 1.0f, 1.0f};
+    p_glGenVertexArrays(1, &vao);
+    p_glGenBuffers(1, &vbo);
+    p_glBindVertexArray(vao);
+    p_glBindBuffer(GL_ARRAY_BUFFER, vbo);
+    p_glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
+    p_glEnableVertexAttribArray(0);
+    p_glVertexAttribPointer(0, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void *)0);
+    p_glEnableVertexAttribArray(1);
+    p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void *)(2 * sizeof(float)));
+    double t0 = now_s();
+    p_glDrawArrays(GL_TRIANGLES, 0, 6);
+    p_glFinish();
+    double dt = now_s() - t0;
+    gl_check("postfx draw");
+    float *buf = malloc((size_t)outW * outH * 16);
+    p_glBindTexture(GL_TEXTURE_2D, outTex);
+    p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, buf);
+    gl_check("postfx readback");
+    if (write_file(argv[5], buf, (size_t)outW * outH * 16)) return 5;
+    printf("{\"draw_s\": %.6f}\n", dt);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: gl_harness render|probe ...\n"); return 2; }
     if (!strcmp(argv[1], "render")) return mode_render(argc, argv);
     if (!strcmp(argv[1], "probe")) return mode_probe(argc, argv);
+    if (!strcmp(argv[1], "postfx")) return mode_postfx(argc, argv);
     fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
 }

@@ -176,6 +176,32 @@ void main() {
     print("  [probes] written", flush=True)
 
 
+def make_taa():
+    """TAA resolve fixture: the reference's taaFs.glsl + outputVs.glsl run on
+    llvmpipe through gl_harness' postfx mode, fed with two consecutive oracle renders of the C2
+    scene (the second with the objects moved, as history) and the first one's gNormal."""
+    R = "/root/reference/shader/"
+    sc = scenes.make_scene(2, host.generate_aabb)
+    out = {}
+    for tag, (W, H, fc, blend) in {"a": (96, 64, 5, 0.1), "b": (50, 37, 0, 0.5), "c": (64, 48, 3, 0.25)}.items():
+        p = sc.params(width=W, height=H)
+        cur, _, nrm, _ = O.render(sc, p)
+        moved = scenes.make_scene(2, host.generate_aabb)
+        moved.objects["position"][:, 0] += 0.07
+        host.generate_aabb(moved.objects)
+        hist, _, _, _ = O.render(moved, p)
+        jx, jy = host.taa_jitter(fc, W, H)
+        res = O.run_postfx(R + "outputVs.glsl", R + "taaFs.glsl", W, H,
+                           [("uCurrentFrame", cur, dict(linear=True)), ("uHistory", hist, dict(linear=True, clamp=True)),
+                            ("gNormal", nrm.astype(np.float32), dict(half=True))],
+                           [("uBlendFactor", float(blend)), ("uJitterX", float(jx)), ("uJitterY", float(jy))])
+        out[f"{tag}_current"], out[f"{tag}_history"], out[f"{tag}_normal"] = cur, hist, nrm
+        out[f"{tag}_params"] = np.array([fc, blend, jx, jy], dtype=np.float64)
+        out[f"{tag}_out"] = res
+    np.savez_compressed(os.path.join(OUT, "taa.npz"), **out)
+    print("  [taa] written", flush=True)
+
+
 def make_surface_probes():
     """rgba16f imageStore rounding + cubemap sampling through a render-mode job with a tiny
     custom shader is not needed: both are exercised by the c5/nan fixtures.  (Kept as a hook.)"""
@@ -188,11 +214,13 @@ def main():
     args = ap.parse_args()
     if not O.harness_available():
         sys.exit("gl_harness or /root/reference is not available: goldens can only be generated in the build container")
-    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes"]
+    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa"]
     for nme in names:
         print(f"== {nme}", flush=True)
         if nme == "probes":
             make_probes()
+        elif nme == "taa":
+            make_taa()
         else:
             make_config(nme, args.skip_fullres)
 
