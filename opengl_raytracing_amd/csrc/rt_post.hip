@@ -4,17 +4,26 @@
 // bandwidth-bound kernel: 56 B of compulsory HBM traffic per pixel (current 16 + history 16 +
 // gNormal 8 read, 16 written) against ~150 flops.
 //
-// Layout: 256-thread workgroup = 32x8 pixels; the current frame's 34x10 tile (1-texel halo, the
-// 3x3 neighbourhood clamp and the jittered bilinear tap both live in it) is staged once in LDS with
-// coalesced 16-B loads; history (4 taps, normally collapsing onto one texel) and the two gNormal
-// taps come straight from L1/L2.  One float4 store per lane.
+// Layout: 256-thread workgroup = 64x4 pixels, one lane per pixel, 16-B loads and one float4 store per
+// lane.  The 3x3 neighbourhood, the jittered bilinear tap, history's 4 taps (normally collapsing onto
+// one texel) and the gNormal tap(s) are served by L1/L2 (RT_TAA_LDS=1 stages the current tile + halo in
+// LDS instead: measured equal).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RT_TAA_LDS
+#define RT_TAA_LDS 0   // 1: stage the current-frame tile (+halo) in LDS; 0: neighbourhood straight from L1/L2.
+#endif                // Measured equal within noise (29-31 us @1080p for every tile shape): the pass is limited by the
+                      // memory pipeline, not by how the 3x3 taps are fetched; the simpler form is the default.
+
 namespace {
 
-constexpr int TX = 32, TY = 8, HALO = 1, LW = TX + 2 * HALO, LH = TY + 2 * HALO;
+#ifndef RT_TAA_TX
+#define RT_TAA_TX 64
+#endif
+constexpr int TX = RT_TAA_TX, TY = 256 / RT_TAA_TX, HALO = 1;
+[[maybe_unused]] constexpr int LW = TX + 2 * HALO, LH = TY + 2 * HALO;
 
 __device__ __forceinline__ int wrapi(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
 __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); }
@@ -31,25 +40,33 @@ __global__ __launch_bounds__(256) void rt_taa_resolve_kernel(const float4 *__res
                                                              const uint2 *__restrict__ normal,   // half4 per pixel
                                                              float4 *__restrict__ out, int W, int H, float blendFactor,
                                                              float jitterX, float jitterY) {
+#if RT_TAA_LDS
     __shared__ float4 tile[LH][LW];
+#endif
     const int bx = blockIdx.x * TX, by = blockIdx.y * TY;
     // stage the current-frame tile; texels outside the image are stored with REPEAT addressing (what the
     // bilinear tap needs); the 3x3 clamp below substitutes 0 for them itself (texelFetch out of range)
+#if RT_TAA_LDS
     for (int k = threadIdx.x; k < LW * LH; k += 256) {
         const int lx = k % LW, ly = k / LW;
         const int gx = wrapi(bx + lx - HALO, W), gy = wrapi(by + ly - HALO, H);
         tile[ly][lx] = current[(size_t)gy * W + gx];
     }
     __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#endif
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int i = bx + tx, j = by + ty;
     if (i >= W || j >= H) return;
 
     auto cur_at = [&](int x, int y) -> rgb {   // REPEAT-addressed current texel (x, y may be any integer)
         const int lx = x - bx + HALO, ly = y - by + HALO;
         float4 q;
+#if RT_TAA_LDS
         if (lx >= 0 && lx < LW && ly >= 0 && ly < LH) q = tile[ly][lx];
-        else q = current[(size_t)wrapi(y, H) * W + wrapi(x, W)];
+        else
+#endif
+        q = current[(size_t)wrapi(y, H) * W + wrapi(x, W)];
+        (void)lx; (void)ly;
         rgb r; r.x = q.x; r.y = q.y; r.z = q.z; return r;
     };
 
@@ -86,7 +103,11 @@ __global__ __launch_bounds__(256) void rt_taa_resolve_kernel(const float4 *__res
         for (int dy = -1; dy <= 1; dy++) {
             const int x = i + dx, y = j + dy;
             const bool inb = x >= 0 && y >= 0 && x < W && y < H;
+#if RT_TAA_LDS
             const float4 q = tile[ty + dy + HALO][tx + dx + HALO];
+#else
+            const float4 q = current[(size_t)clampi(y, H) * W + clampi(x, W)];
+#endif
             const float nx = inb ? q.x : 0.0f, ny = inb ? q.y : 0.0f, nz = inb ? q.z : 0.0f;
             mn.x = fminf(mn.x, nx); mn.y = fminf(mn.y, ny); mn.z = fminf(mn.z, nz);
             mx.x = fmaxf(mx.x, nx); mx.y = fmaxf(mx.y, ny); mx.z = fmaxf(mx.z, nz);
@@ -97,7 +118,8 @@ __global__ __launch_bounds__(256) void rt_taa_resolve_kernel(const float4 *__res
     {
         const int px = wrapi((int)floorf(u * (float)W), W), py = wrapi((int)floorf(v * (float)H), H);
         const int cx = wrapi((int)floorf(ju * (float)W), W), cy = wrapi((int)floorf(jv * (float)H), H);
-        const uint2 pn = normal[(size_t)py * W + px], cn = normal[(size_t)cy * W + cx];
+        const uint2 pn = normal[(size_t)py * W + px];
+        const uint2 cn = (cx == px && cy == py) ? pn : normal[(size_t)cy * W + cx];   // sub-texel jitter: same texel
         const float pnx = __half2float(__ushort_as_half((unsigned short)(pn.x & 0xffffu))), pny = __half2float(__ushort_as_half((unsigned short)(pn.x >> 16)));
         const float pnz = __half2float(__ushort_as_half((unsigned short)(pn.y & 0xffffu)));
         const float cnx = __half2float(__ushort_as_half((unsigned short)(cn.x & 0xffffu))), cny = __half2float(__ushort_as_half((unsigned short)(cn.x >> 16)));
