@@ -211,6 +211,15 @@ int rt_taa_resolve(rt_context *ctx, const void *dCurrent, const void *dHistory, 
 /* uJitterX / uJitterY of ForwardShadingPipeline.cpp:241-242 (global.cpp:41-51's haltonSequence). */
 int rt_taa_jitter(int frameCount, int width, int height, float *jitterX, float *jitterY);
 
+/* ---- bloom: brightness extract (threshold), `iterations` alternating 9-tap
+ *      Gaussian passes on rgba16f targets starting horizontal, combine scene + bloom*strength
+ *      (/root/reference/shader/{brightness_extractFS,gaussian_blurFs,bloom_combineFs}.glsl;
+ *      ForwardShadingPipeline.cpp:189-228 uses threshold 1.0, 10 iterations, strength 0.5).
+ *      dScene = gColor (rgba32f), dOut = combined rgba32f (what the reference draws to the default
+ *      framebuffer, before display quantisation); may not alias.  Asynchronous on hipStream. */
+int rt_bloom(rt_context *ctx, const void *dScene, void *dOut, int width, int height, float threshold,
+             float strength, int iterations, void *hipStream);
+
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);

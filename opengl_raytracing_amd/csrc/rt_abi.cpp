@@ -50,6 +50,8 @@ struct rt_context {
     unsigned fbAge = 0;                        // frames since that geometry was first seen
     hipStream_t fbStream = nullptr;
     hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (stream switches wait on it)
+    void *dBloom[2] = {nullptr, nullptr};      // rgba16f ping-pong targets of rt_bloom
+    size_t capBloomPx = 0;
     bool feedback = true;
     std::string err;
 };
@@ -235,7 +237,7 @@ int rt_destroy(rt_context *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
-                    c->dTileCost, c->dTileOrder};
+                    c->dTileCost, c->dTileOrder, c->dBloom[0], c->dBloom[1]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -454,6 +456,28 @@ int rt_taa_resolve(rt_context *c, const void *dCurrent, const void *dHistory, co
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
     HIP_TRY(c, rt_launch_taa_resolve(dCurrent, dHistory, dNormal, dOut, width, height, blendFactor, jitterX, jitterY, s));
+    return RT_OK;
+}
+
+int rt_bloom(rt_context *c, const void *dScene, void *dOut, int width, int height, float threshold, float strength,
+             int iterations, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!dScene || !dOut || width <= 0 || height <= 0 || iterations < 0) return fail(c, RT_ERR_INVALID_ARG, "bad rt_bloom arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    const size_t npx = (size_t)width * height;
+    if (npx > c->capBloomPx) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (int k = 0; k < 2; k++) {
+            if (c->dBloom[k]) HIP_TRY(c, hipFree(c->dBloom[k]));
+            c->dBloom[k] = nullptr;
+        }
+        c->capBloomPx = 0;
+        HIP_TRY(c, hipMalloc(&c->dBloom[0], npx * 8));
+        HIP_TRY(c, hipMalloc(&c->dBloom[1], npx * 8));
+        c->capBloomPx = npx;
+    }
+    HIP_TRY(c, rt_launch_bloom(dScene, c->dBloom[0], c->dBloom[1], dOut, width, height, threshold, strength, iterations, s));
     return RT_OK;
 }
 

@@ -52,5 +52,7 @@ void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, 
 hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dOrder, int nTiles, hipStream_t s);
 hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
                                  float blend, float jx, float jy, hipStream_t s);
+hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out, int W, int H, float threshold, float strength,
+                           int iterations, hipStream_t s);
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
                                   int stripRows, int stripCount, size_t rankStrideBytes, hipStream_t s);

@@ -146,3 +146,90 @@ hipError_t rt_launch_taa_resolve(const void *current, const void *history, const
                        (const uint2 *)normal, (float4 *)out, W, H, blend, jx, jy);
     return hipGetLastError();
 }
+
+// =========================================================================================
+// Bloom: brightness_extractFS.glsl, gaussian_blurFs.glsl, bloom_combineFs.glsl as
+// driven by /root/reference/src/ForwardShadingPipeline.cpp:189-228.  Intermediate targets are rgba16f
+// (:67-88) and the reference's GL rounds render-target writes toward zero, so every pass stores
+// RTZ halfs; all taps sit on texel centres (LINEAR returns the texel), CLAMP_TO_EDGE at the borders.
+// Each pass is a pure streaming kernel (8 B/px in + 8 B/px out): 16-byte accesses (two pixels per
+// lane), 256-thread workgroups over rows; the vertical pass walks columns through L2.
+// =========================================================================================
+namespace {
+
+__device__ __forceinline__ unsigned f2h_rtz_u(float f) {
+    unsigned u = __float_as_uint(f);
+    unsigned s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (a == 0x7f800000u) ? (s | 0x7c00u) : (s | 0x7e00u | ((a >> 13) & 0x1ffu));
+    if (a >= 0x47800000u) return s | 0x7bffu;
+    if (a >= 0x38800000u) return s | ((a - 0x38000000u) >> 13);
+    if (a < 0x33800000u) return s;
+    unsigned e = a >> 23, m = (a & 0x7fffffu) | 0x800000u;
+    return s | (m >> (126u - e));
+}
+__device__ __forceinline__ float h2f_u(unsigned h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xffffu))); }
+__device__ __forceinline__ uint2 pack_half4(float r, float g, float b) {
+    return make_uint2(f2h_rtz_u(r) | (f2h_rtz_u(g) << 16), f2h_rtz_u(b) | (0x3c00u << 16));
+}
+
+}  // namespace
+
+// brightness extract (brightness_extractFS.glsl:11-19)
+__global__ __launch_bounds__(256) void rt_bloom_extract_kernel(const float4 *__restrict__ scene, uint2 *__restrict__ out,
+                                                               size_t n, float threshold) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const float4 c = scene[k];
+        const float brightness = (c.z * 0.0722f + c.y * 0.7152f) + c.x * 0.2126f;
+        out[k] = (brightness > threshold) ? pack_half4(c.x, c.y, c.z) : make_uint2(0u, 0x3c00u << 16);
+    }
+}
+
+// one separable 9-tap pass (gaussian_blurFs.glsl:8-26)
+template <bool HORIZONTAL>
+__global__ __launch_bounds__(256) void rt_bloom_blur_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, int W, int H) {
+    const float w0 = 0.227027f, w1 = 0.1945946f, w2 = 0.1216216f, w3 = 0.054054f, w4 = 0.016216f;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= W || j >= H) return;
+    auto tap = [&](int t) -> uint2 {
+        const int x = HORIZONTAL ? min(max(i + t, 0), W - 1) : i, y = HORIZONTAL ? j : min(max(j + t, 0), H - 1);
+        return in[(size_t)y * W + x];
+    };
+    const uint2 c = tap(0);
+    float r = h2f_u(c.x) * w0, g = h2f_u(c.x >> 16) * w0, b = h2f_u(c.y) * w0;
+    auto acc = [&](int t, float w) {
+        const uint2 p = tap(t), m = tap(-t);
+        r += h2f_u(p.x) * w; g += h2f_u(p.x >> 16) * w; b += h2f_u(p.y) * w;      // result += tex(+i)*w
+        r += h2f_u(m.x) * w; g += h2f_u(m.x >> 16) * w; b += h2f_u(m.y) * w;      // result += tex(-i)*w
+    };
+    acc(1, w1); acc(2, w2); acc(3, w3); acc(4, w4);
+    out[(size_t)j * W + i] = pack_half4(r, g, b);
+}
+
+// combine (bloom_combineFs.glsl:10-14)
+__global__ __launch_bounds__(256) void rt_bloom_combine_kernel(const float4 *__restrict__ scene, const uint2 *__restrict__ bloom,
+                                                               float4 *__restrict__ out, size_t n, float strength) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const float4 s = scene[k];
+        const uint2 bl = bloom[k];
+        out[k] = make_float4(s.x + h2f_u(bl.x) * strength, s.y + h2f_u(bl.x >> 16) * strength, s.z + h2f_u(bl.y) * strength, 1.0f);
+    }
+}
+
+hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out, int W, int H, float threshold, float strength,
+                           int iterations, hipStream_t s) {
+    const size_t n = (size_t)W * H;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    uint2 *a = (uint2 *)tmpA, *b = (uint2 *)tmpB;
+    hipLaunchKernelGGL(rt_bloom_extract_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)scene, a, n, threshold);
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    bool horizontal = true;                                       // ForwardShadingPipeline.cpp:207
+    for (int it = 0; it < iterations; it++) {
+        if (horizontal) hipLaunchKernelGGL(rt_bloom_blur_kernel<true>, grid, dim3(256), 0, s, a, b, W, H);
+        else hipLaunchKernelGGL(rt_bloom_blur_kernel<false>, grid, dim3(256), 0, s, a, b, W, H);
+        uint2 *t = a; a = b; b = t;
+        horizontal = !horizontal;
+    }
+    hipLaunchKernelGGL(rt_bloom_combine_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)scene, a, (float4 *)out, n, strength);
+    return hipGetLastError();
+}

@@ -32,7 +32,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
     "rt_count_rays", "rt_debug_stats", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
-    "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_strip_local_rows", "rt_deinterleave",
 ]
 
 RT_OK = 0
@@ -82,6 +82,7 @@ def load_library(build_if_missing=True):
     cf = ctypes.c_float
     lib.rt_taa_resolve.argtypes = [vp, vp, vp, vp, vp, ci, ci, cf, cf, cf, vp]
     lib.rt_taa_jitter.argtypes = [ci, ci, ci, P(cf), P(cf)]
+    lib.rt_bloom.argtypes = [vp, vp, vp, ci, ci, cf, cf, ci, vp]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     for name in EXPORTS:
@@ -261,6 +262,11 @@ class RayTracer:
         self._check(self.lib.rt_taa_resolve(self.ctx, ctypes.c_void_p(d_current), ctypes.c_void_p(d_history),
                                             ctypes.c_void_p(d_normal), ctypes.c_void_p(d_out), width, height, blend, jx, jy,
                                             ctypes.c_void_p(stream) if stream else None), "rt_taa_resolve")
+
+    def bloom(self, d_scene, d_out, width, height, threshold=1.0, strength=0.5, iterations=10, stream=None):
+        """Bloom chain on device surfaces (raw device pointers as ints)."""
+        self._check(self.lib.rt_bloom(self.ctx, ctypes.c_void_p(d_scene), ctypes.c_void_p(d_out), width, height, threshold,
+                                      strength, iterations, ctypes.c_void_p(stream) if stream else None), "rt_bloom")
 
     def debug_stats(self):
         out = (ctypes.c_uint64 * 4)()

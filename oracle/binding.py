@@ -204,3 +204,30 @@ def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=Fals
                     f.write(struct.pack("<32si4f", name.encode(), 2 if len(val) == 2 else 4, *v))
         subprocess.run([HARNESS, "postfx", vs_path, fs_path, job, out], check=True, capture_output=True)
         return np.fromfile(out, dtype=np.float32).reshape(out_h, out_w, 4)
+
+
+def bloom(scene, threshold=1.0, strength=0.5, iterations=10, keep=False):
+    """CPU restatement of the reference's bloom chain (extract, `iterations` alternating blurs starting
+    horizontal, combine).  scene f32[h,w,4] -> combined f32[h,w,4] (and the intermediate half
+    textures when keep=True)."""
+    lib = load()
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.orc_bloom_extract.argtypes = [vp, ci, ci, cf, vp]
+    lib.orc_bloom_blur.argtypes = [vp, ci, ci, ci, vp]
+    lib.orc_bloom_combine.argtypes = [vp, vp, ci, ci, cf, vp]
+    scene = np.ascontiguousarray(scene, dtype=np.float32)
+    h, w = scene.shape[:2]
+    a = np.zeros((h, w, 4), dtype=np.uint16)
+    b = np.zeros_like(a)
+    lib.orc_bloom_extract(_ptr(scene), w, h, threshold, _ptr(a))
+    stages = [a.copy()]
+    horizontal = 1
+    for _ in range(iterations):
+        lib.orc_bloom_blur(_ptr(a), w, h, horizontal, _ptr(b))
+        a, b = b, a
+        horizontal ^= 1
+        if keep:
+            stages.append(a.copy())
+    out = np.zeros((h, w, 4), dtype=np.float32)
+    lib.orc_bloom_combine(_ptr(scene), _ptr(a), w, h, strength, _ptr(out))
+    return (out, [s.view(np.float16) for s in stages]) if keep else out

@@ -94,3 +94,74 @@ void orc_taa_jitter(int frameCount, int W, int H, float *jx, float *jy) {
     *jx = halton_host(frameCount % 8, 2) * 0.5f / (float)W;
     *jy = halton_host(frameCount % 8, 3) * 0.5f / (float)H;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Bloom: /root/reference/shader/brightness_extractFS.glsl, gaussian_blurFs.glsl,
+ * bloom_combineFs.glsl as driven by /root/reference/src/ForwardShadingPipeline.cpp:189-228
+ * (textures :67-88: two rgba16f ping-pong targets, LINEAR, CLAMP_TO_EDGE; scene = outputTex rgba32f,
+ * LINEAR, REPEAT).  All taps fall on texel centres, so LINEAR filtering returns the texel (up to the
+ * rasteriser's TexCoords ulps, see the TAA note); render-target writes round fp32 -> fp16 toward zero
+ * (pinned by tests/golden/bloom.npz).
+ * ------------------------------------------------------------------------------------------- */
+/* render-target write fp32 -> fp16: round toward zero, like imageStore */
+static uint16_t f2h_rt(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    uint32_t s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(s | (a == 0x7f800000u ? 0x7c00u : (0x7e00u | ((a >> 13) & 0x1ffu))));
+    if (a >= 0x47800000u) return (uint16_t)(s | 0x7bffu);
+    if (a >= 0x38800000u) return (uint16_t)(s | ((a - 0x38000000u) >> 13));
+    if (a < 0x33800000u) return (uint16_t)s;
+    uint32_t e = a >> 23, m = (a & 0x7fffffu) | 0x800000u;
+    return (uint16_t)(s | (m >> (126u - e)));
+}
+static float h2f(uint16_t h) {
+    uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31, m = h & 1023, u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else { int sh = 0; while (!(m & 1024)) { m <<= 1; sh++; } m &= 1023; u = s | ((uint32_t)(113 - sh) << 23) | (m << 13); }
+    } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else u = s | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+/* brightness extract (brightness_extractFS.glsl:11-19): scene rgba32f -> rgba16f bits */
+void orc_bloom_extract(const float *scene, int W, int H, float threshold, uint16_t *out) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < W * H; k++) {
+        const float *c = scene + (size_t)k * 4;
+        float brightness = (c[2] * 0.0722f + c[1] * 0.7152f) + c[0] * 0.2126f;
+        uint16_t *o = out + (size_t)k * 4;
+        if (brightness > threshold) { o[0] = f2h_rt(c[0]); o[1] = f2h_rt(c[1]); o[2] = f2h_rt(c[2]); }
+        else { o[0] = o[1] = o[2] = 0; }
+        o[3] = 0x3c00u;
+    }
+}
+
+/* one separable 9-tap pass (gaussian_blurFs.glsl:8-26), CLAMP_TO_EDGE, rgba16f in/out */
+void orc_bloom_blur(const uint16_t *in, int W, int H, int horizontal, uint16_t *out) {
+    static const float w[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < H; j++)
+        for (int i = 0; i < W; i++) {
+            float r[3];
+            const uint16_t *c = in + ((size_t)j * W + i) * 4;
+            for (int ch = 0; ch < 3; ch++) r[ch] = h2f(c[ch]) * w[0];
+            for (int t = 1; t < 5; t++) {
+                int xp = horizontal ? clampi2(i + t, W) : i, yp = horizontal ? j : clampi2(j + t, H);
+                int xm = horizontal ? clampi2(i - t, W) : i, ym = horizontal ? j : clampi2(j - t, H);
+                const uint16_t *p = in + ((size_t)yp * W + xp) * 4, *m = in + ((size_t)ym * W + xm) * 4;
+                for (int ch = 0; ch < 3; ch++) { r[ch] += h2f(p[ch]) * w[t]; r[ch] += h2f(m[ch]) * w[t]; }
+            }
+            uint16_t *o = out + ((size_t)j * W + i) * 4;
+            o[0] = f2h_rt(r[0]); o[1] = f2h_rt(r[1]); o[2] = f2h_rt(r[2]); o[3] = 0x3c00u;
+        }
+}
+
+/* combine (bloom_combineFs.glsl:10-14): scene + bloom * strength, fp32 out */
+void orc_bloom_combine(const float *scene, const uint16_t *bloom, int W, int H, float strength, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < W * H; k++) {
+        for (int ch = 0; ch < 3; ch++) out[(size_t)k * 4 + ch] = scene[(size_t)k * 4 + ch] + h2f(bloom[(size_t)k * 4 + ch]) * strength;
+        out[(size_t)k * 4 + 3] = 1.0f;
+    }
+}

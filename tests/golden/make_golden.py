@@ -202,6 +202,37 @@ def make_taa():
     print("  [taa] written", flush=True)
 
 
+def make_bloom():
+    """Bloom fixture: the reference's extract / blur / combine fragment shaders chained
+    on llvmpipe exactly like ForwardShadingPipeline.cpp:189-228 (threshold 1.0, 10 alternating blur passes
+    starting horizontal, strength 0.5), on an oracle render of the C2 scene scaled into HDR range."""
+    R = "/root/reference/shader/"
+    VS = R + "outputVs.glsl"
+    sc = scenes.make_scene(2, host.generate_aabb)
+    out = {}
+    for tag, (W, H, gain) in {"a": (96, 64, 2.5), "b": (50, 37, 4.0)}.items():
+        cur, _, _, _ = O.render(sc, sc.params(width=W, height=H))
+        cur = (cur * np.float32(gain)).astype(np.float32)
+        cur[..., 3] = 1.0
+        tex = O.run_postfx(VS, R + "brightness_extractFS.glsl", W, H, [("hdrTexture", cur, dict(linear=True))],
+                           [("threshold", 1.0)], out_half=True)
+        stages = [tex]
+        horizontal = True
+        for _ in range(10):
+            tex = O.run_postfx(VS, R + "gaussian_blurFs.glsl", W, H, [("image", tex, dict(half=True, linear=True, clamp=True))],
+                               [("horizontal", int(horizontal))], out_half=True)
+            stages.append(tex)
+            horizontal = not horizontal
+        comb = O.run_postfx(VS, R + "bloom_combineFs.glsl", W, H,
+                            [("scene", cur, dict(linear=True)), ("bloomBlur", tex, dict(half=True, linear=True, clamp=True))],
+                            [("bloomStrength", 0.5)])
+        out[f"{tag}_scene"] = cur
+        out[f"{tag}_stages"] = np.stack(stages).astype(np.float16)      # exact: the targets are rgba16f
+        out[f"{tag}_combined"] = comb
+    np.savez_compressed(os.path.join(OUT, "bloom.npz"), **out)
+    print("  [bloom] written", flush=True)
+
+
 def make_surface_probes():
     """rgba16f imageStore rounding + cubemap sampling through a render-mode job with a tiny
     custom shader is not needed: both are exercised by the c5/nan fixtures.  (Kept as a hook.)"""
@@ -214,13 +245,15 @@ def main():
     args = ap.parse_args()
     if not O.harness_available():
         sys.exit("gl_harness or /root/reference is not available: goldens can only be generated in the build container")
-    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa"]
+    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom"]
     for nme in names:
         print(f"== {nme}", flush=True)
         if nme == "probes":
             make_probes()
         elif nme == "taa":
             make_taa()
+        elif nme == "bloom":
+            make_bloom()
         else:
             make_config(nme, args.skip_fullres)
 
