@@ -152,24 +152,23 @@ hipError_t rt_launch_taa_resolve(const void *current, const void *history, const
 // driven by /root/reference/src/ForwardShadingPipeline.cpp:189-228.  Intermediate targets are rgba16f
 // (:67-88) and the reference's GL rounds render-target writes toward zero, so every pass stores
 // RTZ halfs; all taps sit on texel centres (LINEAR returns the texel), CLAMP_TO_EDGE at the borders.
-// Each pass is a pure streaming kernel (8 B/px in + 8 B/px out): 16-byte accesses (two pixels per
-// lane), 256-thread workgroups over rows; the vertical pass walks columns through L2.
+// The chain runs as fused horizontal+vertical pairs (rt_bloom_hv_kernel, below); the single-pass kernels
+// remain for odd / zero iteration counts.
 // =========================================================================================
 namespace {
 
-__device__ __forceinline__ unsigned f2h_rtz_u(float f) {
-    unsigned u = __float_as_uint(f);
-    unsigned s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
-    if (a >= 0x7f800000u) return (a == 0x7f800000u) ? (s | 0x7c00u) : (s | 0x7e00u | ((a >> 13) & 0x1ffu));
-    if (a >= 0x47800000u) return s | 0x7bffu;
-    if (a >= 0x38800000u) return s | ((a - 0x38000000u) >> 13);
-    if (a < 0x33800000u) return s;
-    unsigned e = a >> 23, m = (a & 0x7fffffu) | 0x800000u;
-    return s | (m >> (126u - e));
+// fp32 -> fp16 toward zero in hardware: v_cvt_pkrtz_f16_f32 is IEEE round-toward-zero (overflow saturates to
+// +-65504, fp16 denormals kept -- the kernel runs with the default f16 denormal mode), i.e. the same function
+// as the oracle's software orc_float_to_half_rtz on every non-NaN input; NaNs stay NaNs (payload not compared).
+typedef __fp16 rt_h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pkrtz_u(float lo, float hi) {
+    union { rt_h2v h; unsigned u; } c;
+    c.h = __builtin_amdgcn_cvt_pkrtz(lo, hi);
+    return c.u;
 }
 __device__ __forceinline__ float h2f_u(unsigned h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xffffu))); }
 __device__ __forceinline__ uint2 pack_half4(float r, float g, float b) {
-    return make_uint2(f2h_rtz_u(r) | (f2h_rtz_u(g) << 16), f2h_rtz_u(b) | (0x3c00u << 16));
+    return make_uint2(cvt_pkrtz_u(r, g), cvt_pkrtz_u(b, 1.0f));
 }
 
 }  // namespace
@@ -215,21 +214,135 @@ __global__ __launch_bounds__(256) void rt_bloom_combine_kernel(const float4 *__r
     }
 }
 
+// Fused horizontal+vertical pass pair (one blur "iteration pair" of ForwardShadingPipeline.cpp:207-216):
+// a 64x24-pixel workgroup tile stages its 72x32 input patch (4-texel apron each way, CLAMP_TO_EDGE applied
+// while staging, in image space) in LDS as halfs, runs the horizontal pass into a second LDS array --
+// rounded to fp16 toward zero exactly where the unfused chain stores its rgba16f target -- then the
+// vertical pass from LDS.  Both passes use register sliding windows: a lane owns 8 consecutive outputs
+// along the blur axis (6 for the vertical pass), so it reads 2 (2.3) texels per output instead of 9 and
+// converts each half once.  Lane->row mapping with odd-ish row strides (73 / 65 texels) keeps the
+// ds_read_b64 / ds_write_b64 of 16 consecutive lanes on distinct banks.
+// FIRST folds the brightness extract into the staging (reads the rgba32f scene), LAST folds the combine
+// into the store (writes rgba32f).  HBM traffic per pair: 8 B in + 8 B out per pixel (+ apron re-reads
+// served by L2) instead of 32 B for two unfused passes.
+namespace {
+constexpr int FX = 64, FY = 24, AP = 4, IW = FX + 2 * AP, IH = FY + 2 * AP;   // 72 x 32 patch
+constexpr int IWP = IW + 1, FXP = FX + 1;                                     // padded LDS row strides
+constexpr int HSPAN = 8, VSPAN = 6;                                           // outputs per lane
+static_assert(IH * (FX / HSPAN) == 256 && FX * (FY / VSPAN) == 256, "one work item per thread in both passes");
+}
+
+template <int N>
+__device__ __forceinline__ void blur_window(const float (&r)[N + 8], const float (&g)[N + 8], const float (&b)[N + 8], int k,
+                                            float &orr, float &og, float &ob) {
+    const float w0 = 0.227027f, w1 = 0.1945946f, w2 = 0.1216216f, w3 = 0.054054f, w4 = 0.016216f;
+    const float w[5] = {w0, w1, w2, w3, w4};
+    const int c = k + 4;
+    float ar = r[c] * w0, ag = g[c] * w0, ab = b[c] * w0;         // gaussian_blurFs.glsl:13
+#pragma unroll
+    for (int t = 1; t < 5; t++) {                                 // :15-24: result += tex(+t)*w; result += tex(-t)*w
+        ar += r[c + t] * w[t]; ag += g[c + t] * w[t]; ab += b[c + t] * w[t];
+        ar += r[c - t] * w[t]; ag += g[c - t] * w[t]; ab += b[c - t] * w[t];
+    }
+    orr = ar; og = ag; ob = ab;
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void rt_bloom_hv_kernel(const void *__restrict__ inV, const float4 *__restrict__ scene,
+                                                          void *__restrict__ outV, int W, int H, float threshold, float strength) {
+    // one LDS array, used twice: the input patch (halfs; patch (r,c) <-> image (clamp(y0+r-4), clamp(x0+c-4))),
+    // then -- once every lane holds its window in registers -- the horizontal-pass result (halfs, RTZ) for
+    // patch rows 0..IH-1, tile columns 0..FX-1.  18.7 KB per workgroup: 8 workgroups (32 waves) per CU.
+    __shared__ uint2 sin_[IH * IWP];
+    uint2 *sh_ = sin_;
+    const int x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
+    // ---- stage the input patch (coalesced along rows)
+    for (int k = threadIdx.x; k < IW * IH; k += 256) {
+        const int lx = k % IW, ly = k / IW;
+        const int gx = min(max(x0 + lx - AP, 0), W - 1), gy = min(max(y0 + ly - AP, 0), H - 1);
+        uint2 v;
+        if (FIRST) {     // brightness_extractFS.glsl:11-19 on the fly
+            const float4 c = scene[(size_t)gy * W + gx];
+            const float brightness = (c.z * 0.0722f + c.y * 0.7152f) + c.x * 0.2126f;
+            v = (brightness > threshold) ? pack_half4(c.x, c.y, c.z) : make_uint2(0u, 0x3c00u << 16);
+        } else {
+            v = ((const uint2 *)inV)[(size_t)gy * W + gx];
+        }
+        sin_[ly * IWP + lx] = v;
+    }
+    __syncthreads();
+    {   // ---- horizontal pass: lane -> patch row, 8 consecutive columns
+        const int row = threadIdx.x % IH, grp = threadIdx.x / IH;
+        float r[HSPAN + 8], g[HSPAN + 8], b[HSPAN + 8];
+#pragma unroll
+        for (int c = 0; c < HSPAN + 8; c++) {
+            const uint2 v = sin_[row * IWP + grp * HSPAN + c];
+            r[c] = h2f_u(v.x); g[c] = h2f_u(v.x >> 16); b[c] = h2f_u(v.y);
+        }
+        __syncthreads();     // every window is in registers: the patch storage may be overwritten
+#pragma unroll
+        for (int k = 0; k < HSPAN; k++) {
+            float orr, og, ob;
+            blur_window<HSPAN>(r, g, b, k, orr, og, ob);
+            sh_[row * FXP + grp * HSPAN + k] = pack_half4(orr, og, ob);
+        }
+    }
+    __syncthreads();
+    {   // ---- vertical pass: lane -> column, 6 consecutive rows
+        const int lx = threadIdx.x % FX, seg = threadIdx.x / FX;
+        const int x = x0 + lx;
+        float r[VSPAN + 8], g[VSPAN + 8], b[VSPAN + 8];
+#pragma unroll
+        for (int c = 0; c < VSPAN + 8; c++) {
+            const uint2 v = sh_[(seg * VSPAN + c) * FXP + lx];
+            r[c] = h2f_u(v.x); g[c] = h2f_u(v.x >> 16); b[c] = h2f_u(v.y);
+        }
+#pragma unroll
+        for (int k = 0; k < VSPAN; k++) {
+            const int y = y0 + seg * VSPAN + k;
+            if (x >= W || y >= H) continue;
+            float orr, og, ob;
+            blur_window<VSPAN>(r, g, b, k, orr, og, ob);
+            const uint2 hv = pack_half4(orr, og, ob);                // the rgba16f store of the vertical pass
+            if (LAST) {      // bloom_combineFs.glsl:10-14
+                const float4 sc = scene[(size_t)y * W + x];
+                ((float4 *)outV)[(size_t)y * W + x] = make_float4(sc.x + h2f_u(hv.x) * strength, sc.y + h2f_u(hv.x >> 16) * strength,
+                                                                  sc.z + h2f_u(hv.y) * strength, 1.0f);
+            } else {
+                ((uint2 *)outV)[(size_t)y * W + x] = hv;
+            }
+        }
+    }
+}
+
 hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out, int W, int H, float threshold, float strength,
                            int iterations, hipStream_t s) {
     const size_t n = (size_t)W * H;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     uint2 *a = (uint2 *)tmpA, *b = (uint2 *)tmpB;
-    hipLaunchKernelGGL(rt_bloom_extract_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)scene, a, n, threshold);
-    dim3 grid((W + 63) / 64, (H + 3) / 4);
-    bool horizontal = true;                                       // ForwardShadingPipeline.cpp:207
-    for (int it = 0; it < iterations; it++) {
-        if (horizontal) hipLaunchKernelGGL(rt_bloom_blur_kernel<true>, grid, dim3(256), 0, s, a, b, W, H);
-        else hipLaunchKernelGGL(rt_bloom_blur_kernel<false>, grid, dim3(256), 0, s, a, b, W, H);
-        uint2 *t = a; a = b; b = t;
-        horizontal = !horizontal;
+    const float4 *sc = (const float4 *)scene;
+    const int pairs = iterations / 2;
+    const bool odd = (iterations & 1) != 0;
+    dim3 fgrid((W + FX - 1) / FX, (H + FY - 1) / FY), grid((W + 63) / 64, (H + 3) / 4);
+    if (pairs == 0) {            // 0 or 1 iterations: the unfused kernels
+        hipLaunchKernelGGL(rt_bloom_extract_kernel, dim3(blocks), dim3(256), 0, s, sc, a, n, threshold);
+        if (odd) { hipLaunchKernelGGL(rt_bloom_blur_kernel<true>, grid, dim3(256), 0, s, a, b, W, H); a = b; }
+        hipLaunchKernelGGL(rt_bloom_combine_kernel, dim3(blocks), dim3(256), 0, s, sc, a, (float4 *)out, n, strength);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(rt_bloom_combine_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)scene, a, (float4 *)out, n, strength);
+    for (int p = 0; p < pairs; p++) {
+        const bool first = p == 0, last = (p == pairs - 1) && !odd;
+        void *dst = last ? out : (void *)b;
+        if (first && last) hipLaunchKernelGGL((rt_bloom_hv_kernel<true, true>), fgrid, dim3(256), 0, s, (const void *)a, sc, dst, W, H, threshold, strength);
+        else if (first) hipLaunchKernelGGL((rt_bloom_hv_kernel<true, false>), fgrid, dim3(256), 0, s, (const void *)a, sc, dst, W, H, threshold, strength);
+        else if (last) hipLaunchKernelGGL((rt_bloom_hv_kernel<false, true>), fgrid, dim3(256), 0, s, (const void *)a, sc, dst, W, H, threshold, strength);
+        else hipLaunchKernelGGL((rt_bloom_hv_kernel<false, false>), fgrid, dim3(256), 0, s, (const void *)a, sc, dst, W, H, threshold, strength);
+        if (!last) { uint2 *t = a; a = b; b = t; }
+    }
+    if (odd) {                   // trailing horizontal pass, then the combine
+        hipLaunchKernelGGL(rt_bloom_blur_kernel<true>, grid, dim3(256), 0, s, a, b, W, H);
+        hipLaunchKernelGGL(rt_bloom_combine_kernel, dim3(blocks), dim3(256), 0, s, sc, b, (float4 *)out, n, strength);
+    }
     return hipGetLastError();
 }

@@ -57,12 +57,26 @@ def test_bloom_hip_bit_exact_vs_oracle(tracer, host, oracle):
     g = load_golden("bloom")
     rng = np.random.default_rng(5)
     cases = [(g["a_scene"], 1.0, 0.5, 10), (g["b_scene"], 1.0, 0.5, 10), (g["a_scene"], 0.2, 1.5, 3), (g["b_scene"], 1.0, 0.5, 0)]
-    for (w, h) in [(1, 1), (3, 70), (129, 5), (200, 113)]:
+    cases += [(g["a_scene"], 0.5, 0.75, it) for it in (1, 2, 4, 7)]     # every fused/unfused pairing of the chain
+    for (w, h) in [(1, 1), (3, 70), (129, 5), (200, 113), (64, 16), (65, 17)]:
         sc = (rng.uniform(0, 1, (h, w, 4)) ** 4 * 8).astype(np.float32)
         if w > 8:
             sc[h // 2, w // 2, 0] = np.inf
             sc[0, 1, 1] = np.nan
         cases.append((sc, 1.0, 0.5, 10))
+    # fp16 round-toward-zero edge values through the extract store (the kernels convert with v_cvt_pkrtz_f16_f32,
+    # the oracle in software): denormal halfs, the normal/denormal and overflow boundaries, both signs; green = 1
+    # keeps every texel above the threshold and strength 2^40 makes the stored half recoverable from the output
+    edge = np.array([0.0, 2.0 ** -25, 2.0 ** -24, 1.5 * 2.0 ** -24, 2.0 ** -24 * 1023.9, 2.0 ** -14, 2.0 ** -14 * (1 - 2.0 ** -12),
+                     6.1e-5, 1.0 / 3.0, 0.1, 1.0009765, 1.00146, 65504.0, 65519.9, 65520.0, 65536.0, 1e5, 3e38, 1e-30, 1e-40],
+                    dtype=np.float32)
+    edge = np.concatenate([edge, -edge, rng.uniform(-7e4, 7e4, 88).astype(np.float32),
+                           (rng.uniform(-1, 1, 128) * 2.0 ** rng.integers(-30, -10, 128)).astype(np.float32)])
+    sc = np.zeros((16, 16, 4), np.float32)
+    sc[..., 0] = edge.reshape(16, 16)
+    sc[..., 1] = 1.0
+    sc[..., 2] = edge.reshape(16, 16)[::-1, ::-1]
+    cases += [(sc, 0.5, 2.0 ** 40, 0), (sc, 0.5, 2.0 ** 20, 2)]
     for scene, thr, strength, iters in cases:
         h, w = scene.shape[:2]
         want = oracle.bloom(scene, thr, strength, iters)

@@ -1,6 +1,7 @@
 """Secondary measurement: the bloom chain (extract + 10 blur passes + combine) at 1080p / 4K on a ray-traced
-frame.  Compulsory HBM traffic of the chain as launched (12 kernels): extract 16+8, each blur 8+8, combine
-16+8+16 = 224 B/pixel."""
+frame.  Compulsory HBM traffic of the chain as launched (5 fused horizontal+vertical kernels): first pair
+16 in + 8 out, three middle pairs 8 + 8, last pair 8 + 16 (scene) in + 16 out = 112 B/pixel (the unfused
+12-kernel chain moved 224 B/pixel)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,6 +28,6 @@ for (w, h) in [(1920, 1080), (3840, 2160)]:
     e1.record(s)
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / K * 1e3
-    gbs = w * h * 224 / (us * 1e-6) / 1e9
-    print(json.dumps({"chain": "rt_bloom (12 kernels)", "size": [w, h], "us": round(us, 1), "algorithmic_GBps": round(gbs, 1),
-                      "hbm_peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 3), "bytes_per_px": 224}), flush=True)
+    gbs = w * h * 112 / (us * 1e-6) / 1e9
+    print(json.dumps({"chain": "rt_bloom (5 fused kernels)", "size": [w, h], "us": round(us, 1), "algorithmic_GBps": round(gbs, 1),
+                      "hbm_peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 3), "bytes_per_px": 112}), flush=True)
