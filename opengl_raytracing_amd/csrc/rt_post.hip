@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256) void rt_bloom_combine_kernel(const float4 *__r
 // a 64x24-pixel workgroup tile stages its 72x32 input patch (4-texel apron each way, CLAMP_TO_EDGE applied
 // while staging, in image space) in LDS as halfs, runs the horizontal pass into a second LDS array --
 // rounded to fp16 toward zero exactly where the unfused chain stores its rgba16f target -- then the
-// vertical pass from LDS.  Both passes use register sliding windows: a lane owns 8 consecutive outputs
-// along the blur axis (6 for the vertical pass), so it reads 2 (2.3) texels per output instead of 9 and
-// converts each half once.  Lane->row mapping with odd-ish row strides (73 / 65 texels) keeps the
+// vertical pass from LDS.  Both passes use register sliding windows: a lane owns 4 consecutive outputs
+// along the blur axis (3 for the vertical pass) on each of two lines, so it reads 3 (3.7) texels per output
+// instead of 9, and the two lines share packed-fp32 arithmetic.  Lane->row mapping with odd-ish row strides (73 / 65 texels) keeps the
 // ds_read_b64 / ds_write_b64 of 16 consecutive lanes on distinct banks.
 // FIRST folds the brightness extract into the staging (reads the rgba32f scene), LAST folds the combine
 // into the store (writes rgba32f).  HBM traffic per pair: 8 B in + 8 B out per pixel (+ apron re-reads
@@ -228,17 +228,20 @@ __global__ __launch_bounds__(256) void rt_bloom_combine_kernel(const float4 *__r
 namespace {
 constexpr int FX = 64, FY = 24, AP = 4, IW = FX + 2 * AP, IH = FY + 2 * AP;   // 72 x 32 patch
 constexpr int IWP = IW + 1, FXP = FX + 1;                                     // padded LDS row strides
-constexpr int HSPAN = 8, VSPAN = 6;                                           // outputs per lane
-static_assert(IH * (FX / HSPAN) == 256 && FX * (FY / VSPAN) == 256, "one work item per thread in both passes");
+constexpr int HSPAN = 4, VSPAN = 3;                                           // outputs per lane and per half of the pair
+static_assert((IH / 2) * (FX / HSPAN) == 256 && (FX / 2) * (FY / VSPAN) == 256, "one work item per thread in both passes");
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
 }
 
+// One 9-tap window on TWO independent lines at once (.x / .y): every multiply and add is a packed fp32
+// instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE, no contraction), which halves the VALU work this
+// VALU-bound kernel issues; the order of operations per line is the reference's.
 template <int N>
-__device__ __forceinline__ void blur_window(const float (&r)[N + 8], const float (&g)[N + 8], const float (&b)[N + 8], int k,
-                                            float &orr, float &og, float &ob) {
-    const float w0 = 0.227027f, w1 = 0.1945946f, w2 = 0.1216216f, w3 = 0.054054f, w4 = 0.016216f;
-    const float w[5] = {w0, w1, w2, w3, w4};
+__device__ __forceinline__ void blur_window2(const rt_f2 (&r)[N + 8], const rt_f2 (&g)[N + 8], const rt_f2 (&b)[N + 8], int k,
+                                             rt_f2 &orr, rt_f2 &og, rt_f2 &ob) {
+    const float w[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
     const int c = k + 4;
-    float ar = r[c] * w0, ag = g[c] * w0, ab = b[c] * w0;         // gaussian_blurFs.glsl:13
+    rt_f2 ar = r[c] * w[0], ag = g[c] * w[0], ab = b[c] * w[0];  // gaussian_blurFs.glsl:13
 #pragma unroll
     for (int t = 1; t < 5; t++) {                                 // :15-24: result += tex(+t)*w; result += tex(-t)*w
         ar += r[c + t] * w[t]; ag += g[c + t] * w[t]; ab += b[c + t] * w[t];
@@ -271,45 +274,52 @@ __global__ __launch_bounds__(256) void rt_bloom_hv_kernel(const void *__restrict
         sin_[ly * IWP + lx] = v;
     }
     __syncthreads();
-    {   // ---- horizontal pass: lane -> patch row, 8 consecutive columns
-        const int row = threadIdx.x % IH, grp = threadIdx.x / IH;
-        float r[HSPAN + 8], g[HSPAN + 8], b[HSPAN + 8];
+    {   // ---- horizontal pass: lane -> patch rows (rp, rp+16), 4 consecutive columns of each
+        const int rp = threadIdx.x % (IH / 2), grp = threadIdx.x / (IH / 2);
+        rt_f2 r[HSPAN + 8], g[HSPAN + 8], b[HSPAN + 8];
 #pragma unroll
         for (int c = 0; c < HSPAN + 8; c++) {
-            const uint2 v = sin_[row * IWP + grp * HSPAN + c];
-            r[c] = h2f_u(v.x); g[c] = h2f_u(v.x >> 16); b[c] = h2f_u(v.y);
+            const uint2 v0 = sin_[rp * IWP + grp * HSPAN + c], v1 = sin_[(rp + IH / 2) * IWP + grp * HSPAN + c];
+            r[c].x = h2f_u(v0.x); g[c].x = h2f_u(v0.x >> 16); b[c].x = h2f_u(v0.y);
+            r[c].y = h2f_u(v1.x); g[c].y = h2f_u(v1.x >> 16); b[c].y = h2f_u(v1.y);
         }
         __syncthreads();     // every window is in registers: the patch storage may be overwritten
 #pragma unroll
         for (int k = 0; k < HSPAN; k++) {
-            float orr, og, ob;
-            blur_window<HSPAN>(r, g, b, k, orr, og, ob);
-            sh_[row * FXP + grp * HSPAN + k] = pack_half4(orr, og, ob);
+            rt_f2 orr, og, ob;
+            blur_window2<HSPAN>(r, g, b, k, orr, og, ob);
+            sh_[rp * FXP + grp * HSPAN + k] = pack_half4(orr.x, og.x, ob.x);
+            sh_[(rp + IH / 2) * FXP + grp * HSPAN + k] = pack_half4(orr.y, og.y, ob.y);
         }
     }
     __syncthreads();
-    {   // ---- vertical pass: lane -> column, 6 consecutive rows
-        const int lx = threadIdx.x % FX, seg = threadIdx.x / FX;
-        const int x = x0 + lx;
-        float r[VSPAN + 8], g[VSPAN + 8], b[VSPAN + 8];
+    {   // ---- vertical pass: lane -> columns (lx, lx+32), 3 consecutive rows of each
+        const int lx = threadIdx.x % (FX / 2), seg = threadIdx.x / (FX / 2);
+        rt_f2 r[VSPAN + 8], g[VSPAN + 8], b[VSPAN + 8];
 #pragma unroll
         for (int c = 0; c < VSPAN + 8; c++) {
-            const uint2 v = sh_[(seg * VSPAN + c) * FXP + lx];
-            r[c] = h2f_u(v.x); g[c] = h2f_u(v.x >> 16); b[c] = h2f_u(v.y);
+            const uint2 v0 = sh_[(seg * VSPAN + c) * FXP + lx], v1 = sh_[(seg * VSPAN + c) * FXP + lx + FX / 2];
+            r[c].x = h2f_u(v0.x); g[c].x = h2f_u(v0.x >> 16); b[c].x = h2f_u(v0.y);
+            r[c].y = h2f_u(v1.x); g[c].y = h2f_u(v1.x >> 16); b[c].y = h2f_u(v1.y);
         }
 #pragma unroll
         for (int k = 0; k < VSPAN; k++) {
             const int y = y0 + seg * VSPAN + k;
-            if (x >= W || y >= H) continue;
-            float orr, og, ob;
-            blur_window<VSPAN>(r, g, b, k, orr, og, ob);
-            const uint2 hv = pack_half4(orr, og, ob);                // the rgba16f store of the vertical pass
-            if (LAST) {      // bloom_combineFs.glsl:10-14
-                const float4 sc = scene[(size_t)y * W + x];
-                ((float4 *)outV)[(size_t)y * W + x] = make_float4(sc.x + h2f_u(hv.x) * strength, sc.y + h2f_u(hv.x >> 16) * strength,
-                                                                  sc.z + h2f_u(hv.y) * strength, 1.0f);
-            } else {
-                ((uint2 *)outV)[(size_t)y * W + x] = hv;
+            if (y >= H) continue;
+            rt_f2 orr, og, ob;
+            blur_window2<VSPAN>(r, g, b, k, orr, og, ob);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int x = x0 + lx + half * (FX / 2);
+                if (x >= W) continue;
+                const uint2 hv = half ? pack_half4(orr.y, og.y, ob.y) : pack_half4(orr.x, og.x, ob.x);   // the rgba16f store
+                if (LAST) {      // bloom_combineFs.glsl:10-14
+                    const float4 sc = scene[(size_t)y * W + x];
+                    ((float4 *)outV)[(size_t)y * W + x] = make_float4(sc.x + h2f_u(hv.x) * strength, sc.y + h2f_u(hv.x >> 16) * strength,
+                                                                      sc.z + h2f_u(hv.y) * strength, 1.0f);
+                } else {
+                    ((uint2 *)outV)[(size_t)y * W + x] = hv;
+                }
             }
         }
     }

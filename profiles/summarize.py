@@ -37,6 +37,8 @@ def main(src, prefix):
     # (2*FETCH_SIZE + WRITE_SIZE) KB -- MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B
     # request on gfx950 (exact for wide streaming reads, an upper bound otherwise); WRITE_SIZE exact.
     cfg = os.environ.get("RT_PROFILE_CFG", "c2")
+    if os.environ.get("RT_PROFILE_PROG", "bench.py") != "bench.py":
+        return      # a secondary chain was profiled: the render kernel's launches there are not bench.py's workload
     for k, cs in res.items():
         if ("render_packet_kernel<false" in k or "render_kernel<false" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             tpath = os.path.join(os.path.dirname(prefix), "traffic.json")
