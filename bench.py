@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=1, help="1 = packet kernel (default), 0 = exhaustive loop")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="N>1: frames overlapping on the device, each on its own render stream (default 3; 1..4)")
+    ap.add_argument("--root-weight", type=int, default=0,
+                    help="N>1: strips rank 0 owns per cycle (others own 1); 0 = autotune over 1,2,3,4,6 on untimed frames")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 control-flow rehearsal on a 1-GPU box: every rank uses cuda:0 and the gather goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
@@ -99,68 +103,28 @@ def main():
     rt.load(sc)
     rt.set_variant(args.variant)
 
-    strip_rows = args.strip_rows or D.default_strip_rows(H, world)
-    plan = D.StripPlan(W, H, strip_rows, world) if world > 1 else D.StripPlan(W, H, H, 1)
-    p = plan.params(base, rank) if world > 1 else base
+    strip_rows = args.strip_rows or D.default_strip_rows(H, world, len(sc.objects))
     dev = torch.device("cuda", local_rank)
-    # Two dedicated (non-null) torch streams.  The render kernel is launched on `s_render` through
-    # the ABI; at N > 1 the RCCL gather and the re-assembly kernels are issued from `s_comm`.
-    # Frames are double-buffered, so frame k's gather (xGMI) overlaps frame k+1's render (compute):
-    #   s_render:  [wait gather k-2] render k -> E_render[k%2]
-    #   s_comm  :  wait E_render[k%2]; gather k; deinterleave k -> E_gather[k%2]
+    red_dev = "cpu" if args.rehearse_on_one_gpu else dev
+    # Dedicated (non-null) torch streams.  The render kernel is launched on a render stream through the ABI; at
+    # N > 1 the RCCL gather and the pack / re-assembly kernels are issued from `s_comm`:
+    #   s_render[k%F]:  [wait slot k-F free] render k -> E_render[k%F]
+    #   s_comm       :  wait E_render[k%F]; peers: pack k (40 -> 30 B/px); gather k; rank 0: unpack + de-interleave k
+    # At N > 1 consecutive frames rotate over F render streams (F frames in flight): a rank's share of a 1080p
+    # frame is a single round of resident waves whose length is its slowest tile (0.25 ms at N = 4 and 8 alike,
+    # tools/gpu_strip_scaling.py), so frame k+1 fills the CUs that frame k's short tiles have already left
+    # (N = 8 share on one GPU: 0.25 ms/frame with F = 1, 0.13 with F = 2, 0.09 with F = 3).
     # The timed region still brackets K complete frames (render + gather + re-assembly, drained).
-    s_render = torch.cuda.Stream(device=dev)
+    F = 1 if world == 1 else max(1, min(4, args.frames_in_flight or 3))
+    s_renders = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    s_render = s_renders[0]
     s_comm = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(s_render)
-    assert s_render.cuda_stream != 0 and s_comm.cuda_stream != 0
+    assert all(st.cuda_stream != 0 for st in s_renders) and s_comm.cuda_stream != 0
     stream = s_render
-    # one packed buffer per rank and pipeline slot: [gColor | gPosition | gNormal] of this rank's strips
-    rank_bufs = [D.alloc_rank_buffer(plan, dev) for _ in range(2 if world > 1 else 1)]
-    views = [D.surface_views(b, plan) for b in rank_bufs]
-    rank_buf = rank_bufs[0]
-    s_col, s_pos, s_nrm = views[0]
-    gathered = [None, None]
     full = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty((world, plan.rank_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         full = [torch.empty((H, W, 4), dtype=dt, device=dev) for dt in (torch.float32, torch.float32, torch.float16)]
-    ev_render = [torch.cuda.Event(), torch.cuda.Event()]
-    ev_gather = [torch.cuda.Event(), torch.cuda.Event()]
-    frame_no = [0]
-
-    def step():
-        k = frame_no[0]
-        frame_no[0] += 1
-        if world == 1:
-            rt.render_to(p, s_col.data_ptr(), s_pos.data_ptr(), s_nrm.data_ptr(), stream=s_render.cuda_stream)
-            return
-        b = k & 1
-        c, q, n = views[b]
-        if k >= 2:
-            s_render.wait_event(ev_gather[b])        # slot b's previous frame has left the buffer
-        rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=s_render.cuda_stream)
-        ev_render[b].record(s_render)
-        with torch.cuda.stream(s_comm):
-            s_comm.wait_event(ev_render[b])
-            if args.rehearse_on_one_gpu:
-                s_comm.synchronize()
-                g = D.gather_rank_buffers(rank_bufs[b].cpu(), plan, rank)
-                if rank == 0:
-                    gathered[b].copy_(g)
-                    D.deinterleave_hip(rt, gathered[b], plan, outs=full, stream=s_comm.cuda_stream)
-            else:
-                g = D.gather_rank_buffers(rank_bufs[b], plan, rank, out=gathered[b])   # ONE RCCL gather per frame
-                if rank == 0:
-                    D.deinterleave_hip(rt, g, plan, outs=full, stream=s_comm.cuda_stream)
-            ev_gather[b].record(s_comm)
-
-    # exact ray count of this rank's pixels (instrumented launch, outside the timed region)
-    my_rays = rt.count_rays(p)
-    red_dev = "cpu" if args.rehearse_on_one_gpu else dev
-    rays_t = torch.tensor([my_rays], dtype=torch.int64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(rays_t)
-    frame_rays = int(rays_t.item())
 
     def fence():
         torch.cuda.synchronize()
@@ -168,15 +132,112 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    class Pipeline:
+        """One strip plan's buffers + the per-frame step.  root_weight = strips rank 0 owns per cycle: its rows
+        stay on rank 0 (never packed, never sent), so a heavier root trades its own render time against the
+        bytes converging on its inbound xGMI links."""
+
+        def __init__(self, root_weight):
+            self.plan = D.StripPlan(W, H, strip_rows, world, root_weight) if world > 1 else D.StripPlan(W, H, H, 1)
+            plan = self.plan
+            self.p = plan.params(base, rank) if world > 1 else base
+            me = rank if world > 1 else None
+            self.bufs = [D.alloc_rank_buffer(plan, dev, me) for _ in range(F)]
+            self.views = [D.surface_views(b, plan, me) for b in self.bufs]
+            # peers: real wire buffers; rank 0: one placeholder (torch's gather wants a contribution from the root)
+            self.wires = [D.alloc_wire_buffer(plan, dev) for _ in range(F if rank > 0 else 1)] if world > 1 else None
+            self.gathered = ([torch.empty((world, plan.wire_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+                             if world > 1 and rank == 0 else [None, None])
+            self.ev_render = [torch.cuda.Event() for _ in range(F)]
+            self.ev_free = [torch.cuda.Event() for _ in range(F)]     # slot's surfaces may be rendered into again
+            self.k = 0
+
+        def step(self):
+            k = self.k
+            self.k += 1
+            plan, p = self.plan, self.p
+            if world == 1:
+                c, q, n = self.views[0]
+                rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=s_render.cuda_stream)
+                return
+            b, g2 = k % F, k & 1      # g2: rank 0's gather target (s_comm is in order, two are plenty)
+            c, q, n = self.views[b]
+            sr = s_renders[b]
+            if k >= F:
+                sr.wait_event(self.ev_free[b])
+            rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=sr.cuda_stream)
+            self.ev_render[b].record(sr)
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(self.ev_render[b])
+                if rank > 0:          # surfaces -> 30 B/pixel wire buffer; once packed the slot is free again
+                    wire = D.pack_wire_hip(rt, self.views[b], self.wires[b], plan, stream=s_comm.cuda_stream)
+                    self.ev_free[b].record(s_comm)
+                else:
+                    wire = self.wires[0]
+                if args.rehearse_on_one_gpu:
+                    s_comm.synchronize()
+                    g = D.gather_wire(wire.cpu(), plan, rank)
+                    if rank == 0:
+                        self.gathered[g2].copy_(g)
+                        g = self.gathered[g2]
+                else:
+                    g = D.gather_wire(wire, plan, rank, out=self.gathered[g2])           # ONE RCCL gather per frame
+                if rank == 0:         # peers' strips from the wire, the root's own rows from its local surfaces
+                    D.unpack_wire_hip(rt, g, plan, outs=full, root_views=self.views[b], stream=s_comm.cuda_stream)
+                    self.ev_free[b].record(s_comm)
+
+        def run(self, n_frames):
+            """n_frames complete frames, drained; wall seconds (max over ranks)."""
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n_frames):
+                self.step()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+    # Root share: autotuned on untimed frames unless --root-weight fixes it.  Every rank sees the same
+    # max-over-ranks times, so every rank picks the same plan.
+    tune = None
+    root_weight = 1
+    if world > 1:
+        if args.root_weight > 0:
+            root_weight = args.root_weight
+        else:
+            tune = {}
+            for w0 in (1, 2, 3, 4, 6):
+                trial = Pipeline(w0)
+                trial.run(12)                                   # LPT order, clocks, RCCL channels
+                tune[w0] = round(min(trial.run(36), trial.run(36)) / 36 * 1e3, 4)   # ms / frame
+                del trial
+            root_weight = min(tune, key=tune.get)
+    pipe = Pipeline(root_weight)
+    plan, p = pipe.plan, pipe.p
+    s_col, s_pos, s_nrm = pipe.views[0]
+    step = pipe.step
+
+    # exact ray count of this rank's pixels (instrumented launch, outside the timed region)
+    my_rays = rt.count_rays(p)
+    rays_t = torch.tensor([my_rays], dtype=torch.int64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(rays_t)
+    frame_rays = int(rays_t.item())
+
     for _ in range(args.warmup):
         step()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
+    for st in s_renders[1:]:
+        st.wait_event(ev0)
     for _ in range(args.steps):
         step()
     if world > 1:
+        for st in s_renders[1:]:
+            s_render.wait_stream(st)
         s_render.wait_stream(s_comm)      # the last frame's gather + re-assembly belongs to the timed region
     ev1.record(stream)
     fence()
@@ -240,7 +301,12 @@ def main():
                                    f"{len(sc.lights)} lights, depth {sc.max_ray_depth}, "
                                    f"{'PCSS' if int(sc.lights['shadowType'][0]) == 2 else 'PCF x4'} shadows",
                        "width": W, "height": H, "max_ray_depth": sc.max_ray_depth,
-                       "parallelism": f"{world} x interleaved {strip_rows}-row strips + one RCCL gather/frame, gather k overlapped with render k+1" if world > 1 else "1 GPU",
+                       "parallelism": (f"{world} ranks x interleaved {strip_rows}-row strips, rank 0 owns {root_weight} of every "
+                                       f"{root_weight + world - 1} (its rows stay local), one RCCL gather/frame of the 30 B/px "
+                                       f"wire format ({plan.wire_bytes * (world - 1)} B into rank 0), {F} frames in flight "
+                                       f"(render streams), gather k overlapped with the renders of the following frames")
+                                      if world > 1 else "1 GPU",
+                       "root_weight": root_weight if world > 1 else None, "root_weight_autotune_ms_per_frame": tune,
                        "rays_per_frame": frame_rays, "rays_per_pixel": round(frame_rays / n_px, 3)},
             "mpx_per_s": round(n_px * args.steps / elapsed / 1e6, 1), "rehearsal": bool(args.rehearse_on_one_gpu),
             "assembled_frame_equals_single_gpu_render": assembled_ok,

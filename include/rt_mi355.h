@@ -111,7 +111,13 @@ typedef struct rt_params {
      * ((ly / stripRows) * stripCount + stripIndex) * stripRows + ly % stripRows.
      * {1,1,0} is the identity (single GPU). */
     int32_t stripRows, stripCount, stripIndex;
-    int32_t reserved[3];
+    int32_t reserved0;
+    /* Unequal strips (a rank that owns stripRows rows out of every stripCycleRows, starting at
+     * stripOffsetRows): when stripCycleRows > 0 local row ly is image row
+     * (ly / stripRows) * stripCycleRows + stripOffsetRows + ly % stripRows
+     * and stripCount / stripIndex are ignored.  0 = the equal-strip rule above, which is the same
+     * formula with stripCycleRows = stripRows * stripCount, stripOffsetRows = stripIndex * stripRows. */
+    int32_t stripCycleRows, stripOffsetRows;
 } rt_params;
 
 typedef struct rt_context rt_context;
@@ -176,6 +182,10 @@ int rt_set_variant(rt_context *ctx, int variant);
  * out[2] candidate objects summed over packets (after packet culling), out[3] 64-object cull
  * passes.  [1..3] are zero for variant 0 (no packet culling). */
 int rt_debug_stats(rt_context *ctx, uint64_t out[4]);
+/* Measured cost (shader clock cycles / 64, summed over the tile's waves) of every workgroup tile of the
+ * last feedback-scheduled rt_render / rt_render_to launch, in raster tile order; synchronises.  Writes up
+ * to cap entries, *nTiles / *tilesX describe the tile grid.  Measurement hook, no reference counterpart. */
+int rt_debug_tile_costs(rt_context *ctx, unsigned *out, int cap, int *nTiles, int *tilesX);
 
 const char *rt_last_error(rt_context *ctx);
 
@@ -230,6 +240,29 @@ int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripInde
 int rt_deinterleave(rt_context *ctx, const void *src, void *dst, int width, int height,
                     int bytesPerPixel, int stripRows, int stripCount, size_t rankStrideBytes,
                     void *hipStream);
+
+/* Wire format for the gather (30 bytes per pixel instead of 40): every surface's alpha is the
+ * constant 1.0 (raytracingCs.glsl:581-583), so a rank ships only
+ *     [ gColor rgb f32 x nPixels | gPosition rgb f32 x nPixels | gNormal rgb f16 x nPixels ]
+ * (rt_wire_bytes(nPixels) bytes, padded to 16) and rank 0 restores rgba with alpha = 1.0 while it
+ * puts the strips back in image order.  No counterpart in the reference (single GPU).
+ * rt_wire_pack: this rank's three surfaces (nPixels each, any row order) -> dWire.
+ * rt_wire_unpack: dWire = stripCount rank buffers rankStrideBytes apart, each packed from
+ * rankPixels pixels (whole strips of `width`); dst* = full width x height surfaces.  The image is
+ * made of cycles of rootStrips strips of rank 0 followed by one strip of each other rank
+ * (rootStrips = 1: the equal interleave).  With dRootColor/dRootPosition/dRootNormal != NULL rank
+ * 0's rows are copied from its own local rgba surfaces (they never travel, wire slot 0 is ignored
+ * and rank 0 may own a larger share: its rt_params use stripRows = rootStrips * stripRows,
+ * stripCycleRows = (rootStrips + stripCount - 1) * stripRows, stripOffsetRows = 0); with NULL they
+ * come from wire slot 0 and rootStrips must be 1.
+ * Device pointers; asynchronous on hipStream (NULL = the context's stream). */
+size_t rt_wire_bytes(size_t nPixels);
+int rt_wire_pack(rt_context *ctx, const void *dColor, const void *dPosition, const void *dNormal, void *dWire,
+                 size_t nPixels, void *hipStream);
+int rt_wire_unpack(rt_context *ctx, const void *dWire, size_t rankStrideBytes, size_t rankPixels,
+                   const void *dRootColor, const void *dRootPosition, const void *dRootNormal, int rootStrips,
+                   void *dColor, void *dPosition, void *dNormal, int width, int height, int stripRows, int stripCount,
+                   void *hipStream);
 
 #ifdef __cplusplus
 }

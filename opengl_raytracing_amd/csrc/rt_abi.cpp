@@ -44,12 +44,19 @@ struct rt_context {
     int variant = 1;   // 1 = wavefront-packet kernel (default), 0 = exhaustive per-lane loop
     unsigned long long lastStats[4] = {0, 0, 0, 0};   // rt_count_rays diagnostics (rt_debug_stats)
     // cost-feedback tile scheduling state (packet kernel)
-    unsigned *dTileCost = nullptr, *dTileOrder = nullptr;
+    // Frames may be issued on several streams (frames in flight overlapping on the device), so the order is
+    // double-buffered: a sort writes the buffer no launch is reading, and later launches wait for it.
+    unsigned *dTileCost = nullptr, *dTileSnap = nullptr, *dTileOrder[2] = {nullptr, nullptr};
+    int fbCur = -1;                            // order buffer new launches read (-1 = raster order)
+    int fbNext = 0;                            // order buffer the pending sort is writing
+    bool sortPending = false;                  // a sort has been enqueued on the context's own stream, not yet adopted
     size_t capTiles = 0;
     int fbTiles = 0, fbTilesX = 0, fbBt = 0;   // geometry the current order was measured on (0 = none)
     unsigned fbAge = 0;                        // frames since that geometry was first seen
-    hipStream_t fbStream = nullptr;
-    hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (stream switches wait on it)
+    struct FbStream { hipStream_t s; hipEvent_t last; };   // last feedback launch issued on each stream seen
+    FbStream fbStreams[4] = {};
+    int nFbStreams = 0;
+    hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (adopted once hipEventQuery says done)
     void *dBloom[2] = {nullptr, nullptr};      // rgba16f ping-pong targets of rt_bloom
     size_t capBloomPx = 0;
     bool feedback = true;
@@ -118,8 +125,13 @@ int validate_params(rt_context *c, const rt_params *p) {
     if (p->width <= 0 || p->height <= 0) return fail(c, RT_ERR_INVALID_ARG, "width/height must be positive");
     if (p->regionW < 0 || p->regionH < 0 || p->x0 < 0 || p->y0 < 0)
         return fail(c, RT_ERR_INVALID_ARG, "negative window");
-    if (p->stripRows <= 0 || p->stripCount <= 0 || p->stripIndex < 0 || p->stripIndex >= p->stripCount)
+    if (p->stripRows <= 0) return fail(c, RT_ERR_INVALID_ARG, "bad strip mapping");
+    if (p->stripCycleRows > 0) {
+        if (p->stripOffsetRows < 0 || p->stripOffsetRows + p->stripRows > p->stripCycleRows)
+            return fail(c, RT_ERR_INVALID_ARG, "bad strip mapping (offset + rows exceed the cycle)");
+    } else if (p->stripCycleRows < 0 || p->stripCount <= 0 || p->stripIndex < 0 || p->stripIndex >= p->stripCount) {
         return fail(c, RT_ERR_INVALID_ARG, "bad strip mapping");
+    }
     if (p->maxRayDepth < 0 || p->maxRayDepth > RT_MAX_DEPTH)
         return fail(c, RT_ERR_INVALID_ARG, "maxRayDepth outside [0, 32]");
     return RT_OK;
@@ -128,6 +140,10 @@ int validate_params(rt_context *c, const rt_params *p) {
 void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
     memset(f, 0, sizeof *f);
     f->p = *p;
+    if (p->stripCycleRows <= 0) {      // equal strips: normalise to the cycle/offset form the kernels use
+        f->p.stripCycleRows = p->stripRows * p->stripCount;
+        f->p.stripOffsetRows = p->stripIndex * p->stripRows;
+    }
     f->nObj = c->nObj;
     f->nLt = c->nLt;
     f->noiseW = c->noiseW;
@@ -146,6 +162,22 @@ void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
     for (int i = 0; i < 4; i++) hemi_local((float)i / 4.0f, halton_host(i, 2), f->sssHemi[i]);   // :320
 }
 
+hipError_t fb_sync_all(rt_context *c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->nFbStreams && e == hipSuccess; i++) e = hipEventSynchronize(c->fbStreams[i].last);
+    if (e == hipSuccess && c->evSort) e = hipEventSynchronize(c->evSort);
+    return e;
+}
+
+hipError_t fb_wait_others(rt_context *c, const rt_context::FbStream *mine, hipStream_t s) {
+    for (int i = 0; i < c->nFbStreams; i++) {
+        if (&c->fbStreams[i] == mine) continue;
+        hipError_t e = hipStreamWaitEvent(s, c->fbStreams[i].last, 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint2 *dNormal,
            unsigned long long *counter, hipStream_t s, bool timed) {
     RtFrame f;
@@ -157,28 +189,56 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
     sc.tileOrder = nullptr;
     sc.tileCost = nullptr;
     if (!c->dCompiled) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene has not been called");
-    // Longest-first tile order from the previous frame's measured tile costs (same window geometry,
-    // same stream).  The first frame of a geometry runs in raster order and only records costs.
+    // Longest-first tile order from the previous frames' measured tile costs (same window geometry, any
+    // stream).  The first frame of a geometry runs in raster order and only records costs.
     bool sortAfter = false;
     int bt = 0, tile = 0, tilesX = 0, nTiles = 0;
+    rt_context::FbStream *mine = nullptr;
     if (c->variant == 1 && c->feedback && !counter && p->regionW > 0 && p->regionH > 0) {
         rt_packet_geometry(c->nObj, p->regionW, p->regionH, &bt, &tile, &tilesX, &nTiles);
         if ((size_t)nTiles > c->capTiles) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->fbStream) HIP_TRY(c, hipStreamSynchronize(c->fbStream));
-            if (c->dTileCost) HIP_TRY(c, hipFree(c->dTileCost));
-            if (c->dTileOrder) HIP_TRY(c, hipFree(c->dTileOrder));
-            c->dTileCost = c->dTileOrder = nullptr;
+            HIP_TRY(c, fb_sync_all(c));
+            for (unsigned **q : {&c->dTileCost, &c->dTileSnap, &c->dTileOrder[0], &c->dTileOrder[1]}) {
+                if (*q) HIP_TRY(c, hipFree(*q));
+                *q = nullptr;
+            }
             c->capTiles = 0;
             c->fbTiles = 0;
+            c->fbCur = -1;
             HIP_TRY(c, hipMalloc((void **)&c->dTileCost, (size_t)nTiles * sizeof(unsigned)));
-            HIP_TRY(c, hipMalloc((void **)&c->dTileOrder, (size_t)nTiles * sizeof(unsigned)));
+            HIP_TRY(c, hipMalloc((void **)&c->dTileSnap, (size_t)nTiles * sizeof(unsigned)));
+            HIP_TRY(c, hipMalloc((void **)&c->dTileOrder[0], (size_t)nTiles * sizeof(unsigned)));
+            HIP_TRY(c, hipMalloc((void **)&c->dTileOrder[1], (size_t)nTiles * sizeof(unsigned)));
             c->capTiles = (size_t)nTiles;
         }
-        if (c->fbStream && c->fbStream != s && c->evSort) HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
-        const bool same = c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt && c->fbStream == s;
-        if (!same) HIP_TRY(c, hipMemsetAsync(c->dTileCost, 0, (size_t)nTiles * sizeof(unsigned), s));
-        sc.tileOrder = same ? c->dTileOrder : nullptr;
+        for (int i = 0; i < c->nFbStreams; i++)
+            if (c->fbStreams[i].s == s) mine = &c->fbStreams[i];
+        if (!mine) {
+            if (c->nFbStreams == 4) {          // more streams than slots: drain and start over (not a hot path)
+                HIP_TRY(c, fb_sync_all(c));
+                c->nFbStreams = 0;
+            }
+            mine = &c->fbStreams[c->nFbStreams++];
+            mine->s = s;
+            if (!mine->last) HIP_TRY(c, hipEventCreateWithFlags(&mine->last, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(mine->last, s));
+        }
+        // The sort runs on the context's own stream, beside the frames; its order is adopted by the first launch
+        // issued after it has completed, so no render stream ever waits for it.
+        if (c->sortPending && hipEventQuery(c->evSort) == hipSuccess) {
+            c->fbCur = c->fbNext;
+            c->sortPending = false;
+        }
+        const bool same = c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt;
+        if (!same) {                           // new geometry: nobody may still be using the old costs / order
+            HIP_TRY(c, fb_wait_others(c, mine, s));
+            if (c->evSort) HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
+            HIP_TRY(c, hipMemsetAsync(c->dTileCost, 0, (size_t)nTiles * sizeof(unsigned), s));
+            c->fbCur = -1;
+            c->sortPending = false;
+            c->fbAge = 0;
+        }
+        sc.tileOrder = c->fbCur >= 0 ? c->dTileOrder[c->fbCur] : nullptr;
         sc.tileCost = c->dTileCost;
         sortAfter = true;
     }
@@ -189,20 +249,24 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         c->timed = true;
     }
     if (sortAfter) {
+        HIP_TRY(c, hipEventRecord(mine->last, s));
         // Tile costs drift slowly from frame to frame: re-sort on the first two frames of a geometry,
         // then every 8th (costs keep accumulating in between, which only smooths the estimate).
-        const bool fresh = !(c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt && c->fbStream == s);
-        if (fresh) c->fbAge = 0;
-        if (c->fbAge < 2 || (c->fbAge & 7u) == 0) {
-            HIP_TRY(c, rt_launch_lpt_sort(c->dTileCost, c->dTileOrder, nTiles, s));
+        if ((c->fbAge < 2 || (c->fbAge & 7u) == 0) && !c->sortPending) {
+            const int next = c->fbCur == 0 ? 1 : 0;
+            // the buffer about to be rewritten was last read before the previous adoption: every stream's last
+            // launch (this one included) is after those reads, and gives the sort this frame's costs
+            for (int i = 0; i < c->nFbStreams; i++) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->fbStreams[i].last, 0));
+            HIP_TRY(c, rt_launch_lpt_sort(c->dTileCost, c->dTileSnap, c->dTileOrder[next], nTiles, c->stream));
             if (!c->evSort) HIP_TRY(c, hipEventCreateWithFlags(&c->evSort, hipEventDisableTiming));
-            HIP_TRY(c, hipEventRecord(c->evSort, s));
+            HIP_TRY(c, hipEventRecord(c->evSort, c->stream));
+            c->fbNext = next;
+            c->sortPending = true;
         }
         c->fbAge++;
         c->fbTiles = nTiles;
         c->fbTilesX = tilesX;
         c->fbBt = bt;
-        c->fbStream = s;
     }
     return RT_OK;
 }
@@ -236,8 +300,13 @@ int rt_destroy(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 4; i++)
+        if (c->fbStreams[i].last) {
+            (void)hipEventSynchronize(c->fbStreams[i].last);
+            (void)hipEventDestroy(c->fbStreams[i].last);
+        }
     void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
-                    c->dTileCost, c->dTileOrder, c->dBloom[0], c->dBloom[1]};
+                    c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -447,6 +516,18 @@ int rt_debug_stats(rt_context *c, uint64_t out[4]) {
     return RT_OK;
 }
 
+int rt_debug_tile_costs(rt_context *c, unsigned *out, int cap, int *nTiles, int *tilesX) {
+    if (!c || !out || cap < 0 || !nTiles || !tilesX) return RT_ERR_INVALID_ARG;
+    *nTiles = c->fbTiles;
+    *tilesX = c->fbTilesX;
+    if (c->fbTiles == 0 || !c->dTileCost) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, fb_sync_all(c));
+    const int n = c->fbTiles < cap ? c->fbTiles : cap;
+    HIP_TRY(c, hipMemcpy(out, c->dTileCost, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_taa_resolve(rt_context *c, const void *dCurrent, const void *dHistory, const void *dNormal, void *dOut, int width,
                    int height, float blendFactor, float jitterX, float jitterY, void *hipStream) {
     if (!c) return RT_ERR_INVALID_ARG;
@@ -505,6 +586,42 @@ int rt_deinterleave(rt_context *c, const void *src, void *dst, int width, int he
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
     HIP_TRY(c, rt_launch_deinterleave(src, dst, width, height, bytesPerPixel, stripRows, stripCount, rankStrideBytes, s));
+    return RT_OK;
+}
+
+size_t rt_wire_bytes(size_t nPixels) { return (nPixels * 30 + 15) / 16 * 16; }
+
+int rt_wire_pack(rt_context *c, const void *dColor, const void *dPosition, const void *dNormal, void *dWire, size_t nPixels,
+                 void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!dColor || !dPosition || !dNormal || !dWire) return fail(c, RT_ERR_INVALID_ARG, "bad wire_pack arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    HIP_TRY(c, rt_launch_wire_pack(dColor, dPosition, dNormal, dWire, nPixels, s));
+    return RT_OK;
+}
+
+int rt_wire_unpack(rt_context *c, const void *dWire, size_t rankStrideBytes, size_t rankPixels, const void *dRootColor,
+                   const void *dRootPosition, const void *dRootNormal, int rootStrips, void *dColor, void *dPosition,
+                   void *dNormal, int width, int height, int stripRows, int stripCount, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!dWire || !dColor || !dPosition || !dNormal || width <= 0 || height <= 0 || stripRows <= 0 || stripCount <= 0 ||
+        rootStrips <= 0)
+        return fail(c, RT_ERR_INVALID_ARG, "bad wire_unpack arguments");
+    const bool rootLocal = dRootColor || dRootPosition || dRootNormal;
+    if (rootLocal && !(dRootColor && dRootPosition && dRootNormal))
+        return fail(c, RT_ERR_INVALID_ARG, "the root's three local surfaces must be given together");
+    if (!rootLocal && rootStrips != 1) return fail(c, RT_ERR_INVALID_ARG, "a larger root share needs the root's local surfaces");
+    // every rank buffer must hold the rank's whole strips, and the f32 / f16 planes must stay aligned
+    const int cycleRows = (rootStrips + stripCount - 1) * stripRows;
+    const int nCycles = (height + cycleRows - 1) / cycleRows;
+    const size_t needPixels = (size_t)nCycles * stripRows * width;
+    if (rankPixels < needPixels || rankStrideBytes % 4 != 0 || rankStrideBytes < rankPixels * 30)
+        return fail(c, RT_ERR_INVALID_ARG, "rank buffers too small or misaligned for this strip plan");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    HIP_TRY(c, rt_launch_wire_unpack(dWire, rankStrideBytes, rankPixels, dRootColor, dRootPosition, dRootNormal,
+                                     rootStrips * stripRows, dColor, dPosition, dNormal, width, height, stripRows, stripCount, s));
     return RT_OK;
 }
 

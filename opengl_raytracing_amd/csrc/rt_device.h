@@ -49,10 +49,15 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
 // Tile geometry of the packet kernel for a given scene size / window (so the ABI layer can size the
 // feedback buffers): workgroup threads, tile edge, tiles per row, total tiles.
 void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles);
-hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dOrder, int nTiles, hipStream_t s);
+hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s);
 hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
                                  float blend, float jx, float jy, hipStream_t s);
 hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out, int W, int H, float threshold, float strength,
                            int iterations, hipStream_t s);
+hipError_t rt_launch_wire_pack(const void *dColor, const void *dPos, const void *dNormal, void *dWire, size_t nPixels,
+                               hipStream_t s);
+hipError_t rt_launch_wire_unpack(const void *dWire, size_t rankStrideBytes, size_t rankPixels, const void *dRootColor,
+                                 const void *dRootPos, const void *dRootNormal, int rootRows, void *dColor, void *dPos,
+                                 void *dNormal, int width, int height, int stripRows, int stripCount, hipStream_t s);
 hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int height, int bytesPerPixel,
                                   int stripRows, int stripCount, size_t rankStrideBytes, hipStream_t s);

@@ -570,7 +570,7 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
     if (i < f.p.regionW && j < f.p.regionH) {
     const int gxI = f.p.x0 + i;
     const int ly = f.p.y0 + j;
-    const int gyI = ((ly / f.p.stripRows) * f.p.stripCount + f.p.stripIndex) * f.p.stripRows + ly % f.p.stripRows;
+    const int gyI = (ly / f.p.stripRows) * f.p.stripCycleRows + f.p.stripOffsetRows + ly % f.p.stripRows;
     const size_t outIdx = (size_t)j * f.p.regionW + i;
     if (gxI >= f.p.width || gyI >= f.p.height) {   // outside the image: GL discards the imageStore
         gColor[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -747,6 +747,65 @@ __global__ void rt_deinterleave_kernel(const U *__restrict__ src, U *__restrict_
 }
 
 // =========================================================================================
+// Wire format of the gather (30 B/pixel: rgb f32 | rgb f32 | rgb f16; alpha is the constant 1.0 on all
+// three surfaces): pack on every rank, unpack + de-interleave on rank 0.  Streaming copies: the
+// 12-byte-per-lane accesses of a wave are contiguous (768 B), the 6-byte ones 384 B.
+// =========================================================================================
+__global__ __launch_bounds__(256) void rt_wire_pack_kernel(const float4 *__restrict__ col, const float4 *__restrict__ pos,
+                                                           const uint2 *__restrict__ nrm, float *__restrict__ wcol,
+                                                           float *__restrict__ wpos, unsigned short *__restrict__ wnrm, size_t n) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const float4 c = col[k], q = pos[k];
+        const uint2 h = nrm[k];
+        wcol[3 * k] = c.x; wcol[3 * k + 1] = c.y; wcol[3 * k + 2] = c.z;
+        wpos[3 * k] = q.x; wpos[3 * k + 1] = q.y; wpos[3 * k + 2] = q.z;
+        wnrm[3 * k] = (unsigned short)(h.x & 0xffffu); wnrm[3 * k + 1] = (unsigned short)(h.x >> 16);
+        wnrm[3 * k + 2] = (unsigned short)(h.y & 0xffffu);
+    }
+}
+
+// Rank-0 side.  Every cycle of rootRows + (stripCount-1)*stripRows image rows starts with the root's own rows
+// -- copied straight from its local rgba surfaces when rootCol != NULL (they never travel), otherwise taken
+// from wire slot 0 like everybody else's -- followed by one strip of each peer, from that peer's wire buffer.
+__global__ __launch_bounds__(256) void rt_wire_unpack_kernel(const unsigned char *__restrict__ wire, size_t rankStrideBytes,
+                                                             size_t rankPixels, const float4 *__restrict__ rootCol,
+                                                             const float4 *__restrict__ rootPos, const uint2 *__restrict__ rootNrm,
+                                                             int rootRows, float4 *__restrict__ col, float4 *__restrict__ pos,
+                                                             uint2 *__restrict__ nrm, int width, int height, int stripRows,
+                                                             int stripCount) {
+    const size_t total = (size_t)width * height;
+    const int cycleRows = rootRows + (stripCount - 1) * stripRows;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t)gridDim.x * 256) {
+        const int y = (int)(k / width), x = (int)(k % width);
+        const int cyc = y / cycleRows, w = y % cycleRows;
+        int rank, ly;
+        if (w < rootRows) {
+            rank = 0;
+            ly = cyc * rootRows + w;
+            if (rootCol) {
+                const size_t pi = (size_t)ly * width + x;
+                col[k] = rootCol[pi];
+                pos[k] = rootPos[pi];
+                nrm[k] = rootNrm[pi];
+                continue;
+            }
+        } else {
+            const int j = w - rootRows;
+            rank = 1 + j / stripRows;
+            ly = cyc * stripRows + j % stripRows;
+        }
+        const size_t pi = (size_t)ly * width + x;
+        const unsigned char *base = wire + (size_t)rank * rankStrideBytes;
+        const float *wc = (const float *)base + 3 * pi;
+        const float *wp = (const float *)(base + rankPixels * 12) + 3 * pi;
+        const unsigned short *wn = (const unsigned short *)(base + rankPixels * 24) + 3 * pi;
+        col[k] = make_float4(wc[0], wc[1], wc[2], 1.0f);
+        pos[k] = make_float4(wp[0], wp[1], wp[2], 1.0f);
+        nrm[k] = make_uint2((unsigned)wn[0] | ((unsigned)wn[1] << 16), (unsigned)wn[2] | (0x3c00u << 16));
+    }
+}
+
+// =========================================================================================
 // Launch wrappers
 // =========================================================================================
 hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint8_t *dLights, int nLt,
@@ -792,20 +851,30 @@ void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, 
 
 // Longest-processing-time-first order from measured tile costs: 256 linear cost bins (descending),
 // counting sort by one 1024-thread workgroup (a frame has at most a few 1e5 tiles).  Order inside a
-// bin is arbitrary -- this is a scheduling hint, never a data dependency.  Costs are cleared for the
-// next frame's accumulation.
-__global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict__ cost, unsigned *__restrict__ order, int nTiles) {
+// bin is arbitrary -- this is a scheduling hint, never a data dependency.  Frames on other streams may
+// be updating `cost` while this runs, so every cost is read ONCE into `snap` and both passes bin the
+// snapshot: `order` is always a permutation of the tiles.  Costs are cleared for the next accumulation.
+__global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict__ cost, unsigned *__restrict__ snap,
+                                                           unsigned *__restrict__ order, int nTiles) {
     __shared__ unsigned bins[256];
     __shared__ unsigned maxCost;
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     if (threadIdx.x == 0) maxCost = 1;
     __syncthreads();
     unsigned mx = 1;
-    for (int i = threadIdx.x; i < nTiles; i += 1024) mx = max(mx, cost[i]);
+    for (int i = threadIdx.x; i < nTiles; i += 1024) {
+        const unsigned c = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        snap[i] = c;
+        mx = max(mx, c);
+    }
     atomicMax(&maxCost, mx);
     __syncthreads();
     const float scale = 255.0f / (float)maxCost;
-    for (int i = threadIdx.x; i < nTiles; i += 1024) atomicAdd(&bins[255 - min(255, (int)((float)cost[i] * scale))], 1u);
+    for (int i = threadIdx.x; i < nTiles; i += 1024) {      // each thread re-reads only what it wrote itself
+        const unsigned b = 255u - (unsigned)min(255, (int)((float)snap[i] * scale));
+        snap[i] = b;
+        atomicAdd(&bins[b], 1u);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned run = 0;
@@ -813,16 +882,15 @@ __global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict_
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nTiles; i += 1024) {
-        const unsigned pos = atomicAdd(&bins[255 - min(255, (int)((float)cost[i] * scale))], 1u);
+        const unsigned pos = atomicAdd(&bins[snap[i]], 1u);
         order[pos] = (unsigned)i;
     }
-    __syncthreads();
     for (int i = threadIdx.x; i < nTiles; i += 1024) cost[i] = 0;
 }
 
-hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dOrder, int nTiles, hipStream_t s) {
+hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s) {
     if (nTiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_lpt_sort_kernel, dim3(1), dim3(1024), 0, s, dCost, dOrder, nTiles);
+    hipLaunchKernelGGL(rt_lpt_sort_kernel, dim3(1), dim3(1024), 0, s, dCost, dSnap, dOrder, nTiles);
     return hipGetLastError();
 }
 
@@ -849,5 +917,28 @@ hipError_t rt_launch_deinterleave(const void *src, void *dst, int width, int hei
     else
         hipLaunchKernelGGL(rt_deinterleave_kernel<unsigned>, dim3(blocks), dim3(256), 0, s, (const unsigned *)src,
                            (unsigned *)dst, rowUnits, height, stripRows, stripCount, strideUnits);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_wire_pack(const void *dColor, const void *dPos, const void *dNormal, void *dWire, size_t nPixels,
+                               hipStream_t s) {
+    if (nPixels == 0) return hipSuccess;
+    size_t blocks = (nPixels + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    unsigned char *w = (unsigned char *)dWire;
+    hipLaunchKernelGGL(rt_wire_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4 *)dColor, (const float4 *)dPos,
+                       (const uint2 *)dNormal, (float *)w, (float *)(w + nPixels * 12), (unsigned short *)(w + nPixels * 24), nPixels);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_wire_unpack(const void *dWire, size_t rankStrideBytes, size_t rankPixels, const void *dRootColor,
+                                 const void *dRootPos, const void *dRootNormal, int rootRows, void *dColor, void *dPos,
+                                 void *dNormal, int width, int height, int stripRows, int stripCount, hipStream_t s) {
+    size_t blocks = ((size_t)width * height + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rt_wire_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned char *)dWire, rankStrideBytes,
+                       rankPixels, (const float4 *)dRootColor, (const float4 *)dRootPos, (const uint2 *)dRootNormal, rootRows,
+                       (float4 *)dColor, (float4 *)dPos, (uint2 *)dNormal, width, height, stripRows, stripCount);
     return hipGetLastError();
 }

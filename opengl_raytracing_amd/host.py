@@ -31,8 +31,9 @@ _LIB = None
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
-    "rt_count_rays", "rt_debug_stats", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
+    "rt_count_rays", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack",
 ]
 
 RT_OK = 0
@@ -73,6 +74,7 @@ def load_library(build_if_missing=True):
     lib.rt_count_rays.argtypes = [vp, P(L.RtParams), P(ctypes.c_uint64)]
     lib.rt_set_variant.argtypes = [vp, ci]
     lib.rt_debug_stats.argtypes = [vp, P(ctypes.c_uint64)]
+    lib.rt_debug_tile_costs.argtypes = [vp, P(ctypes.c_uint32), ci, P(ci), P(ci)]
     lib.rt_last_error.argtypes = [vp]
     lib.rt_last_error.restype = ctypes.c_char_p
     lib.rt_generate_aabb.argtypes = [vp, ci]
@@ -85,6 +87,10 @@ def load_library(build_if_missing=True):
     lib.rt_bloom.argtypes = [vp, vp, vp, ci, ci, cf, cf, ci, vp]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
+    lib.rt_wire_bytes.argtypes = [ctypes.c_size_t]
+    lib.rt_wire_bytes.restype = ctypes.c_size_t
+    lib.rt_wire_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.rt_wire_unpack.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
     for name in EXPORTS:
         if name != "rt_last_error":
             getattr(lib, name).restype = ci
@@ -268,6 +274,18 @@ class RayTracer:
         self._check(self.lib.rt_bloom(self.ctx, ctypes.c_void_p(d_scene), ctypes.c_void_p(d_out), width, height, threshold,
                                       strength, iterations, ctypes.c_void_p(stream) if stream else None), "rt_bloom")
 
+    def tile_costs(self):
+        """(costs[tilesY, tilesX] uint32, cycles/64 per tile) of the last feedback-scheduled launch."""
+        import numpy as _np
+        n, tx = ctypes.c_int(0), ctypes.c_int(0)
+        probe = (ctypes.c_uint32 * 1)()
+        self._check(self.lib.rt_debug_tile_costs(self.ctx, probe, 0, ctypes.byref(n), ctypes.byref(tx)), "rt_debug_tile_costs")
+        if n.value == 0:
+            return _np.zeros((0, 0), dtype=_np.uint32)
+        out = (ctypes.c_uint32 * n.value)()
+        self._check(self.lib.rt_debug_tile_costs(self.ctx, out, n.value, ctypes.byref(n), ctypes.byref(tx)), "rt_debug_tile_costs")
+        return _np.frombuffer(out, dtype=_np.uint32).reshape(-1, tx.value).copy()
+
     def debug_stats(self):
         out = (ctypes.c_uint64 * 4)()
         self._check(self.lib.rt_debug_stats(self.ctx, out), "rt_debug_stats")
@@ -278,3 +296,19 @@ class RayTracer:
         self._check(self.lib.rt_deinterleave(self.ctx, ctypes.c_void_p(d_src), ctypes.c_void_p(d_dst), width,
                                              height, bytes_per_pixel, strip_rows, strip_count, rank_stride_bytes,
                                              ctypes.c_void_p(stream) if stream else None), "rt_deinterleave")
+
+    def wire_pack(self, d_color, d_pos, d_normal, d_wire, n_pixels, stream=None):
+        """This rank's three surfaces -> the 30 B/pixel gather wire format (device pointers as ints)."""
+        self._check(self.lib.rt_wire_pack(self.ctx, ctypes.c_void_p(d_color), ctypes.c_void_p(d_pos), ctypes.c_void_p(d_normal),
+                                          ctypes.c_void_p(d_wire), n_pixels, ctypes.c_void_p(stream) if stream else None),
+                    "rt_wire_pack")
+
+    def wire_unpack(self, d_wire, rank_stride_bytes, rank_pixels, d_color, d_pos, d_normal, width, height, strip_rows,
+                    strip_count, root=None, root_strips=1, stream=None):
+        """Gathered wire buffers -> full rgba surfaces in image order (alpha restored to 1.0).  root = (d_color,
+        d_pos, d_normal) of rank 0's own local surfaces: its rows are copied from there instead of wire slot 0."""
+        r = [ctypes.c_void_p(x) for x in root] if root else [None, None, None]
+        self._check(self.lib.rt_wire_unpack(self.ctx, ctypes.c_void_p(d_wire), rank_stride_bytes, rank_pixels, r[0], r[1], r[2],
+                                            root_strips, ctypes.c_void_p(d_color), ctypes.c_void_p(d_pos),
+                                            ctypes.c_void_p(d_normal), width, height, strip_rows, strip_count,
+                                            ctypes.c_void_p(stream) if stream else None), "rt_wire_unpack")

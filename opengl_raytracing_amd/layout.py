@@ -123,7 +123,9 @@ class RtParams(ctypes.Structure):
         ("stripRows", ctypes.c_int32),
         ("stripCount", ctypes.c_int32),
         ("stripIndex", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 3),
+        ("reserved0", ctypes.c_int32),
+        ("stripCycleRows", ctypes.c_int32),
+        ("stripOffsetRows", ctypes.c_int32),
     ]
 
 

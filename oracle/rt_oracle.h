@@ -37,7 +37,10 @@ typedef struct orc_params {
      * ((ly / stripRows) * stripCount + stripIndex) * stripRows + ly % stripRows.
      * stripCount = 1, stripIndex = 0 is the identity. */
     int32_t stripRows, stripCount, stripIndex;
-    int32_t reserved[3];
+    int32_t reserved0;    /* test-only knob, see orc_render */
+    /* unequal strips: stripCycleRows > 0 -> global row (ly / stripRows) * stripCycleRows +
+     * stripOffsetRows + ly % stripRows (stripCount / stripIndex ignored) */
+    int32_t stripCycleRows, stripOffsetRows;
 } orc_params;
 
 /* Render.  objects: nObj*176 bytes, lights: nLt*96 bytes (std430 layouts,

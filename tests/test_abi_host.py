@@ -19,7 +19,7 @@ HEADER = os.path.join(REPO, "include", "rt_mi355.h")
 
 def declared_symbols():
     text = open(HEADER).read()
-    return sorted(set(re.findall(r"^(?:int|const char \*)\s*\*?(rt_[a-z_0-9]+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?(rt_[a-z_0-9]+)\s*\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol(host):

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, strip_rows, w, h, out_path):
+def _worker(rank, world, port, strip_rows, w, h, out_path, root_weight):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -34,35 +34,51 @@ def _worker(rank, world, port, strip_rows, w, h, out_path):
 
     sc = scenes.make_scene(2, host.generate_aabb)
     base = sc.params(width=w, height=h)
-    plan = D.StripPlan(w, h, strip_rows, world)
+    plan = D.StripPlan(w, h, strip_rows, world, root_weight)
     p = plan.params(base, rank)
     col, pos, nrm, rays = O.render(sc, p, nthreads=2)
-    assert col.shape[0] == plan.max_local_rows
-    buf = D.alloc_rank_buffer(plan, "cpu")
-    vc, vp, vn = D.surface_views(buf, plan)
+    assert col.shape[0] == plan.buffer_rows(rank)
+    buf = D.alloc_rank_buffer(plan, "cpu", rank)
+    vc, vp, vn = D.surface_views(buf, plan, rank)
     vc.copy_(torch.from_numpy(col))
     vp.copy_(torch.from_numpy(pos))
     vn.view(torch.int16).copy_(torch.from_numpy(nrm.view(np.int16)))
-    g = D.gather_rank_buffers(buf, plan, rank)
+    # the frame through the 30 B/pixel wire format (what bench.py sends over xGMI): peers pack, the root's
+    # rows stay local and its gather contribution is a placeholder
+    wire = D.pack_wire_torch((vc, vp, vn), plan) if rank > 0 else torch.zeros(plan.wire_bytes, dtype=torch.uint8)
+    gw = D.gather_wire(wire, plan, rank)
     total = torch.tensor([rays], dtype=torch.int64)
     dist.all_reduce(total)
+    g = None
+    if root_weight == 1:                  # surface-format path (rt_deinterleave's layout): equal strips only
+        g = D.gather_rank_buffers(buf, plan, rank)
     if rank == 0:
-        full = D.deinterleave_torch(g, plan)
-        np.savez(out_path, color=full[0].numpy(), pos=full[1].numpy(), normal=full[2].view(torch.int16).numpy(),
+        assert gw.shape == (world, plan.wire_bytes) and plan.wire_bytes < plan.rank_bytes
+        wfull = D.unpack_wire_torch(gw, plan, root_views=(vc, vp, vn))
+        if root_weight == 1:
+            full = D.deinterleave_torch(g, plan)
+            for a, b in zip(full, wfull):
+                assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "wire path differs from the surface path"
+            # and with the root's rows travelling through wire slot 0 like everybody else's
+            gw[0].copy_(D.pack_wire_torch((vc, vp, vn), plan))
+            for a, b in zip(full, D.unpack_wire_torch(gw, plan)):
+                assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        np.savez(out_path, color=wfull[0].numpy(), pos=wfull[1].numpy(), normal=wfull[2].view(torch.int16).numpy(),
                  rays=int(total.item()))
     else:
-        assert g is None
+        assert g is None and gw is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,strip_rows,size", [(2, 16, (96, 70)), (3, 8, (64, 45))])
-def test_gloo_strip_gather_reproduces_single_frame(tmp_path, world, strip_rows, size):
+@pytest.mark.parametrize("world,strip_rows,size,root_weight", [(2, 16, (96, 70), 1), (3, 8, (64, 45), 1), (2, 8, (64, 70), 2),
+                                                               (3, 8, (48, 61), 3)])
+def test_gloo_strip_gather_reproduces_single_frame(tmp_path, world, strip_rows, size, root_weight):
     from opengl_raytracing_amd import host, scenes
     from oracle import binding as O
     w, h = size
     out = str(tmp_path / "full.npz")
-    mp.spawn(_worker, args=(world, _free_port(), strip_rows, w, h, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), strip_rows, w, h, out, root_weight), nprocs=world, join=True)
     got = np.load(out)
     sc = scenes.make_scene(2, host.generate_aabb)
     col, pos, nrm, rays = O.render(sc, sc.params(width=w, height=h))

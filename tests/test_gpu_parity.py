@@ -202,6 +202,37 @@ def test_strip_tiling_equals_single_render(tracer, host):
             assert bits_equal(out.cpu().numpy(), ref), f"world {world}"
             it = torch.int16 if out.dtype == torch.float16 else torch.int32
             assert torch.equal(out.view(it), chk.view(it))
+        # the same frame through the 30 B/pixel wire format bench.py gathers (rt_wire_pack / rt_wire_unpack)
+        wires = torch.zeros((world, plan.wire_bytes), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            D.pack_wire_hip(tracer, D.surface_views(gathered[r], plan), wires[r], plan)
+            assert torch.equal(wires[r], D.pack_wire_torch(D.surface_views(gathered[r], plan), plan)), f"pack, world {world}"
+        wouts = D.unpack_wire_hip(tracer, wires, plan)
+        tracer.sync()
+        for out, wout in zip(outs, wouts):
+            it = torch.int16 if out.dtype == torch.float16 else torch.int32
+            assert torch.equal(out.view(it), wout.view(it)), f"wire path, world {world}"
+        for a, b in zip(wouts, D.unpack_wire_torch(wires, plan)):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # weighted root: rank 0 owns root_weight strips per cycle and its rows never enter the wire
+    for world, strip_rows, w0 in [(2, 8, 2), (4, 8, 3), (8, 8, 2), (3, 16, 4)]:
+        plan = D.StripPlan(322, 187, strip_rows, world, w0)
+        root = D.alloc_rank_buffer(plan, "cuda", 0)
+        rviews = D.surface_views(root, plan, 0)
+        tracer.render_to(plan.params(base, 0), *(v.data_ptr() for v in rviews))
+        wires = torch.zeros((world, plan.wire_bytes), dtype=torch.uint8, device="cuda")
+        peer = D.alloc_rank_buffer(plan, "cuda", 1)
+        pviews = D.surface_views(peer, plan, 1)
+        for r in range(1, world):
+            tracer.render_to(plan.params(base, r), *(v.data_ptr() for v in pviews))
+            D.pack_wire_hip(tracer, pviews, wires[r], plan)
+        wouts = D.unpack_wire_hip(tracer, wires, plan, root_views=rviews)
+        tracer.sync()
+        torch.cuda.synchronize()
+        for out, ref in zip(wouts, (col, pos, nrm)):
+            assert bits_equal(out.cpu().numpy(), ref), f"weighted root, world {world} w0 {w0}"
+        for a, b in zip(wouts, D.unpack_wire_torch(wires, plan, root_views=rviews)):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
 
 def test_scene_update_every_frame_and_timing(tracer, host, oracle):

@@ -34,7 +34,7 @@ GATES = {
 
 def render_oracle(oracle, scene, params, tan_bits=0):
     p = L.copy_params(params)
-    p.reserved[0] = int(tan_bits)
+    p.reserved0 = int(tan_bits)
     return oracle.render(scene, p)
 
 
