@@ -230,6 +230,24 @@ int rt_taa_jitter(int frameCount, int width, int height, float *jitterX, float *
 int rt_bloom(rt_context *ctx, const void *dScene, void *dOut, int width, int height, float threshold,
              float strength, int iterations, void *hipStream);
 
+/* ---- next row: SSAO -- shader/ssaoFs.glsl:16-46 and ssao_blurFs.glsl:11-29 as driven by AOManager::RenderSSAO
+ *      (AO.cpp:86-117).  dPosition (rgba32f) / dNormal (rgba16f) are the ray kernel's G-buffer surfaces;
+ *      hNoise = the rotation texture (nW x nH rgba32f texels, nW*nH <= 16; AO.cpp:38-51 makes it 4x4),
+ *      hSamples = the 64 kernel samples (AO.cpp:23-36), hProjection / hView = column-major mat4 (the glm
+ *      matrices AO.cpp:91-92 uploads; rt_camera_matrices builds them like Camera.h:36-42); all four are HOST
+ *      pointers, copied at the call.  dOut = width*height floats: the value the fragment shader writes (the
+ *      reference renders it into FBOs without attachments, so upstream nothing consumes it).
+ *      rt_ssao_blur: one separable 9-tap pass (the reference draws a single pass and never sets `horizontal`,
+ *      i.e. vertical).  Asynchronous on hipStream. */
+int rt_ssao(rt_context *ctx, const void *dPosition, const void *dNormal, void *dOut, int width, int height,
+            const float *hNoise, int noiseW, int noiseH, const float *hSamples, const float *hProjection,
+            const float *hView, void *hipStream);
+int rt_ssao_blur(rt_context *ctx, const void *dIn, void *dOut, int width, int height, int horizontal, void *hipStream);
+/* glm::lookAt(Position, Position + Front, Up) and glm::perspective(radians(FOV), aspect, 0.1, 100) of
+ * Camera.h:36-42, column-major, fp32. */
+int rt_camera_matrices(const float position[3], const float front[3], const float up[3], float fovDeg, float aspect,
+                       float view[16], float projection[16]);
+
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);

@@ -58,6 +58,8 @@ struct rt_context {
     int nFbStreams = 0;
     hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (adopted once hipEventQuery says done)
     void *dBloom[2] = {nullptr, nullptr};      // rgba16f ping-pong targets of rt_bloom
+    float *dSsaoDepth = nullptr;               // gPosition.z plane of rt_ssao
+    size_t capSsaoPx = 0;
     size_t capBloomPx = 0;
     bool feedback = true;
     std::string err;
@@ -306,7 +308,7 @@ int rt_destroy(rt_context *c) {
             (void)hipEventDestroy(c->fbStreams[i].last);
         }
     void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
-                    c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1]};
+                    c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1], c->dSsaoDepth};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -563,6 +565,38 @@ int rt_bloom(rt_context *c, const void *dScene, void *dOut, int width, int heigh
 }
 
 const char *rt_last_error(rt_context *c) { return c ? c->err.c_str() : "NULL context"; }
+
+int rt_ssao(rt_context *c, const void *dPosition, const void *dNormal, void *dOut, int width, int height, const float *hNoise,
+            int noiseW, int noiseH, const float *hSamples, const float *hProjection, const float *hView, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!dPosition || !dNormal || !dOut || !hNoise || !hSamples || !hProjection || !hView || width <= 0 || height <= 0)
+        return fail(c, RT_ERR_INVALID_ARG, "bad rt_ssao arguments");
+    if (noiseW <= 0 || noiseH <= 0 || noiseW * noiseH > 16) return fail(c, RT_ERR_TOO_LARGE, "rotation texture larger than 16 texels");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    const size_t npx = (size_t)width * height;
+    if (npx > c->capSsaoPx) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        if (c->dSsaoDepth) HIP_TRY(c, hipFree(c->dSsaoDepth));
+        c->dSsaoDepth = nullptr;
+        c->capSsaoPx = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->dSsaoDepth, npx * sizeof(float)));
+        c->capSsaoPx = npx;
+    }
+    HIP_TRY(c, rt_launch_ssao(dPosition, dNormal, c->dSsaoDepth, dOut, width, height, hNoise, noiseW, noiseH, hSamples, hProjection,
+                              hView, s));
+    return RT_OK;
+}
+
+int rt_ssao_blur(rt_context *c, const void *dIn, void *dOut, int width, int height, int horizontal, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!dIn || !dOut || width <= 0 || height <= 0) return fail(c, RT_ERR_INVALID_ARG, "bad rt_ssao_blur arguments");
+    if (dIn == dOut) return fail(c, RT_ERR_INVALID_ARG, "rt_ssao_blur cannot run in place");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    HIP_TRY(c, rt_launch_ssao_blur(dIn, dOut, width, height, horizontal, s));
+    return RT_OK;
+}
 
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex) {
     if (height < 0 || stripRows <= 0 || stripCount <= 0 || stripIndex < 0 || stripIndex >= stripCount) return RT_ERR_INVALID_ARG;

@@ -3,6 +3,7 @@
 //   rt_generate_aabb   <- GenerateAABBForObject   /root/reference/src/SceneIO.h:75-104
 //   rt_camera_vectors  <- Camera::UpdateVectors   /root/reference/src/Camera.h:26-34
 //   rt_scene_parse     <- SceneIO::Load + ParseObject/ParseLight  SceneIO.h:108-122,145-186
+//   rt_camera_matrices <- Camera::GetViewMatrix / GetProjectionMatrix  Camera.h:36-42
 // glm is not available here; the few glm calls used there are restated in fp32
 // (glm::normalize(v) = v * inversesqrt(dot(v,v)), dot = x*x + y*y + z*z, glm::radians(d) =
 // d * 0.01745329251994329576923690768489f).
@@ -101,6 +102,33 @@ int rt_camera_vectors(float yawDeg, float pitchDeg, float front[3], float right[
     st(front, f);
     st(right, r);
     st(up, u);
+    return RT_OK;
+}
+
+int rt_camera_matrices(const float position[3], const float front[3], const float up[3], float fovDeg, float aspect,
+                       float view[16], float projection[16]) {
+    if (!position || !front || !up || !view || !projection) return RT_ERR_INVALID_ARG;
+    // glm::lookAtRH(eye, center, up) (Camera.h:36-38), m[col*4 + row]
+    const f3 eye = ld(position), center = add(eye, ld(front));
+    const f3 f = nrm(sub(center, eye));
+    const f3 s = nrm(crs(f, ld(up)));
+    const f3 u = crs(s, f);
+    auto dot3 = [](f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    memset(view, 0, 16 * sizeof(float));
+    view[0] = s.x; view[4] = s.y; view[8] = s.z;
+    view[1] = u.x; view[5] = u.y; view[9] = u.z;
+    view[2] = -f.x; view[6] = -f.y; view[10] = -f.z;
+    view[12] = -dot3(s, eye); view[13] = -dot3(u, eye); view[14] = dot3(f, eye);
+    view[15] = 1.0f;
+    // glm::perspectiveRH_NO(radians(FOV), aspect, 0.1, 100) (Camera.h:40-42)
+    const float fovy = fovDeg * 0.01745329251994329576923690768489f, zNear = 0.1f, zFar = 100.0f;
+    const float tanHalf = tanf(fovy / 2.0f);
+    memset(projection, 0, 16 * sizeof(float));
+    projection[0] = 1.0f / (aspect * tanHalf);
+    projection[5] = 1.0f / tanHalf;
+    projection[10] = -(zFar + zNear) / (zFar - zNear);
+    projection[11] = -1.0f;
+    projection[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
     return RT_OK;
 }
 

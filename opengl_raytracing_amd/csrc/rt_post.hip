@@ -11,6 +11,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifndef RT_TAA_LDS
 #define RT_TAA_LDS 0   // 1: stage the current-frame tile (+halo) in LDS; 0: neighbourhood straight from L1/L2.
@@ -354,5 +355,140 @@ hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out,
         hipLaunchKernelGGL(rt_bloom_blur_kernel<true>, grid, dim3(256), 0, s, a, b, W, H);
         hipLaunchKernelGGL(rt_bloom_combine_kernel, dim3(blocks), dim3(256), 0, s, sc, b, (float4 *)out, n, strength);
     }
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// SSAO: ssaoFs.glsl:16-46 + ssao_blurFs.glsl:11-29 as driven by
+// /root/reference/src/AO.cpp:86-117.  G-buffer consumer: gPosition (rgba32f) and gNormal (rgba16f) as the ray
+// kernel wrote them, NEAREST with the default REPEAT wrap (ForwardShadingPipeline.cpp:115-126).  Same fp32
+// expression shapes as oracle/rt_post_oracle.c::orc_ssao (pinned bit for bit to the shader on llvmpipe).
+// MI355X mapping: the 64 kernel samples, both matrices and the 4x4 rotation texture are kernel arguments
+// (1.2 KB): wave-uniform, so they arrive as SGPR operands by s_load; a wave owns an 8x8 pixel tile so its
+// 64 x 64 depth gathers (4 B out of every 16 B texel) stay in a few L1/L2 lines.
+// =========================================================================================
+#ifndef RT_SSAO_UNROLL
+#define RT_SSAO_UNROLL 8
+#endif
+#ifndef RT_SSAO_TILE_W
+#define RT_SSAO_TILE_W 8          // wave tile width in pixels (height = 64 / width)
+#endif
+struct RtSsaoArgs {
+    float samples[64][3];
+    float projection[16], view[16];
+    float noise[16][4];
+    int nW, nH, W, H;
+};
+
+namespace {
+__device__ __forceinline__ int ssao_nearest_repeat(float u, int size) {
+    if ((size & (size - 1)) == 0) return ((int)floorf(u * (float)size)) & (size - 1);
+    float fr = u - floorf(u);
+    if (!(fr < 1.0f)) fr = 0.99999994f;
+    if (!(fr >= 0.0f)) fr = 0.0f;
+    return (int)(fr * (float)size);
+}
+__device__ __forceinline__ void ssao_nrm3(float x, float y, float z, float &ox, float &oy, float &oz) {
+    const float d = (z * z + y * y) + x * x;
+    const float r = 1.0f / sqrtf(d);
+    ox = x * r; oy = y * r; oz = z * r;
+}
+}  // namespace
+
+// gPosition.z as a dense plane: the 64 depth gathers per pixel then touch 4x fewer cache lines
+__global__ __launch_bounds__(256) void rt_ssao_depth_kernel(const float4 *__restrict__ position, float *__restrict__ depth, size_t n) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) depth[k] = position[k].z;
+}
+
+__global__ __launch_bounds__(256) void rt_ssao_kernel(const float4 *__restrict__ position, const uint2 *__restrict__ normal,
+                                                      const float *__restrict__ depth, float *__restrict__ out, const RtSsaoArgs a) {
+    // 256 threads = 4 waves, each an 8x8 tile of a 32x8 block
+    constexpr int TW = RT_SSAO_TILE_W, TH = 64 / TW;
+    const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int i = blockIdx.x * (4 * TW) + wave * TW + (ln % TW), j = blockIdx.y * TH + (ln / TW);
+    const int W = a.W, H = a.H;
+    if (i >= W || j >= H) return;
+    const float u = ((float)i + 0.5f) / (float)W, v = ((float)j + 0.5f) / (float)H;
+    const size_t self = (size_t)ssao_nearest_repeat(v, H) * W + ssao_nearest_repeat(u, W);
+    const float4 fp = position[self];
+    const uint2 nh = normal[self];
+    float nx, ny, nz, rx, ry, rz;
+    ssao_nrm3(h2f_u(nh.x), h2f_u(nh.x >> 16), h2f_u(nh.y), nx, ny, nz);
+    const float nu = u * 200.0f, nv = v * 200.0f;                                       // ssaoFs.glsl:14,20
+    const int nt = ssao_nearest_repeat(nv, a.nH) * a.nW + ssao_nearest_repeat(nu, a.nW);
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++)       // per-lane pick from the SGPR-resident texture (<= 16 texels)
+        if (k == nt) { qx = a.noise[k][0]; qy = a.noise[k][1]; qz = a.noise[k][2]; }
+    ssao_nrm3(qx, qy, qz, rx, ry, rz);
+    const float d = (rz * nz + ry * ny) + rx * nx;
+    float tx, ty, tz;
+    ssao_nrm3(rx - nx * d, ry - ny * d, rz - nz * d, tx, ty, tz);
+    const float bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;
+    float occlusion = 0.0f;
+    const float *V = a.view, *P = a.projection;
+#pragma unroll RT_SSAO_UNROLL
+    for (int k = 0; k < 64; k++) {
+        const float s0 = a.samples[k][0], s1 = a.samples[k][1], s2 = a.samples[k][2];
+        float px = (tx * s0 + bx * s1) + nx * s2, py = (ty * s0 + by * s1) + ny * s2, pz = (tz * s0 + bz * s1) + nz * s2;
+        px = fp.x + px * 0.5f; py = fp.y + py * 0.5f; pz = fp.z + pz * 0.5f;
+        float vw[4], of[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) vw[r] = ((V[r] * px + V[4 + r] * py) + V[8 + r] * pz) + V[12 + r] * 1.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) of[r] = ((P[r] * vw[0] + P[4 + r] * vw[1]) + P[8 + r] * vw[2]) + P[12 + r] * vw[3];
+        float ox = of[0] / of[3], oy = of[1] / of[3];
+        ox = ox * 0.5f + 0.5f;
+        oy = oy * 0.5f + 0.5f;
+        const float sampleDepth = depth[(size_t)ssao_nearest_repeat(oy, H) * W + ssao_nearest_repeat(ox, W)];
+        const float x = 0.5f / fabsf(fp.z - sampleDepth);
+        const float tt = fminf(fmaxf(x, 0.0f), 1.0f);
+        const float rangeCheck = tt * (tt * (3.0f - 2.0f * tt));
+        occlusion += (sampleDepth >= pz + 0.025f ? 1.0f : 0.0f) * rangeCheck;
+    }
+    out[(size_t)j * W + i] = 1.0f - occlusion / 64.0f;
+}
+
+template <bool HORIZONTAL>
+__global__ __launch_bounds__(256) void rt_ssao_blur_kernel(const float *__restrict__ in, float *__restrict__ out, int W, int H) {
+    const float wgt[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= W || j >= H) return;
+    const float u = ((float)i + 0.5f) / (float)W, v = ((float)j + 0.5f) / (float)H;
+    const float tx = 1.0f / (float)W, ty = 1.0f / (float)H;
+    float r = in[(size_t)ssao_nearest_repeat(v, H) * W + ssao_nearest_repeat(u, W)] * wgt[0];
+#pragma unroll
+    for (int k = 1; k < 5; k++) {
+        const float du = HORIZONTAL ? tx * (float)k : 0.0f, dv = HORIZONTAL ? 0.0f : ty * (float)k;
+        r += in[(size_t)ssao_nearest_repeat(v + dv, H) * W + ssao_nearest_repeat(u + du, W)] * wgt[k];
+        r += in[(size_t)ssao_nearest_repeat(v - dv, H) * W + ssao_nearest_repeat(u - du, W)] * wgt[k];
+    }
+    out[(size_t)j * W + i] = r;
+}
+
+hipError_t rt_launch_ssao(const void *position, const void *normal, void *depthPlane, void *out, int W, int H, const float *noise,
+                          int nW, int nH, const float *samples, const float *projection, const float *view, hipStream_t s) {
+    RtSsaoArgs a;
+    memset(&a, 0, sizeof a);
+    memcpy(a.samples, samples, sizeof a.samples);
+    memcpy(a.projection, projection, sizeof a.projection);
+    memcpy(a.view, view, sizeof a.view);
+    memcpy(a.noise, noise, (size_t)nW * nH * 4 * sizeof(float));
+    a.nW = nW; a.nH = nH; a.W = W; a.H = H;
+    constexpr int TW = RT_SSAO_TILE_W, TH = 64 / TW;
+    dim3 grid((W + 4 * TW - 1) / (4 * TW), (H + TH - 1) / TH);
+    const size_t n = (size_t)W * H;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(rt_ssao_depth_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4 *)position, (float *)depthPlane, n);
+    hipLaunchKernelGGL(rt_ssao_kernel, grid, dim3(256), 0, s, (const float4 *)position, (const uint2 *)normal,
+                       (const float *)depthPlane, (float *)out, a);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_ssao_blur(const void *in, void *out, int W, int H, int horizontal, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    if (horizontal) hipLaunchKernelGGL(rt_ssao_blur_kernel<true>, grid, dim3(256), 0, s, (const float *)in, (float *)out, W, H);
+    else hipLaunchKernelGGL(rt_ssao_blur_kernel<false>, grid, dim3(256), 0, s, (const float *)in, (float *)out, W, H);
     return hipGetLastError();
 }

@@ -32,7 +32,8 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
     "rt_count_rays", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
-    "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
+    "rt_camera_matrices", "rt_strip_local_rows", "rt_deinterleave",
     "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack",
 ]
 
@@ -85,6 +86,9 @@ def load_library(build_if_missing=True):
     lib.rt_taa_resolve.argtypes = [vp, vp, vp, vp, vp, ci, ci, cf, cf, cf, vp]
     lib.rt_taa_jitter.argtypes = [ci, ci, ci, P(cf), P(cf)]
     lib.rt_bloom.argtypes = [vp, vp, vp, ci, ci, cf, cf, ci, vp]
+    lib.rt_ssao.argtypes = [vp, vp, vp, vp, ci, ci, P(cf), ci, ci, P(cf), P(cf), P(cf), vp]
+    lib.rt_ssao_blur.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    lib.rt_camera_matrices.argtypes = [P(cf), P(cf), P(cf), cf, cf, P(cf), P(cf)]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     lib.rt_wire_bytes.argtypes = [ctypes.c_size_t]
@@ -119,6 +123,39 @@ def camera_vectors(yaw_deg=-90.0, pitch_deg=0.0):
     if rc:
         raise RtError(rc, "rt_camera_vectors")
     return tuple(f), tuple(r), tuple(u)
+
+
+def camera_matrices(position, front, up, fov_deg=45.0, aspect=16.0 / 9.0):
+    """Camera::GetViewMatrix / GetProjectionMatrix (/root/reference/src/Camera.h:36-42) -> (view[16],
+    projection[16]) float32, column-major."""
+    a3 = lambda v: (ctypes.c_float * 3)(*[float(x) for x in v])
+    view, proj = (ctypes.c_float * 16)(), (ctypes.c_float * 16)()
+    rc = load_library().rt_camera_matrices(a3(position), a3(front), a3(up), fov_deg, aspect, view, proj)
+    if rc:
+        raise RtError(rc, "rt_camera_matrices")
+    return np.array(view, dtype=np.float32), np.array(proj, dtype=np.float32)
+
+
+def ssao_kernel(seed=0x55A0):
+    """The 64 hemisphere samples and the 4x4 rotation texture of AOManager::InitSSAO (AO.cpp:23-51), same
+    construction; the reference draws them from std::default_random_engine (implementation-defined
+    sequence), this generator uses SplitMix64 -- they are inputs of rt_ssao either way."""
+    from .scenes import SplitMix64
+    rng = SplitMix64(seed)
+    samples = np.zeros((64, 3), dtype=np.float32)
+    for i in range(64):
+        s = np.array([rng.uniform(0, 1) * 2.0 - 1.0, rng.uniform(0, 1) * 2.0 - 1.0, rng.uniform(0, 1)], dtype=np.float32)
+        s = s / np.float32(np.sqrt(np.dot(s, s)))
+        s = s * np.float32(rng.uniform(0, 1))
+        scale = np.float32(i) / np.float32(64.0)
+        scale = np.float32(0.1) + (scale * scale) * np.float32(0.9)
+        samples[i] = s * scale
+    noise = np.zeros((4, 4, 4), dtype=np.float32)      # uploaded as GL_RGB into RGBA32F: alpha reads 1
+    for k in range(16):
+        noise[k // 4, k % 4, 0] = rng.uniform(0, 1) * 2.0 - 1.0
+        noise[k // 4, k % 4, 1] = rng.uniform(0, 1) * 2.0 - 1.0
+    noise[..., 3] = 1.0
+    return samples, noise
 
 
 def parse_scene(text, max_objects=512, max_lights=64):
@@ -253,6 +290,12 @@ class RayTracer:
         self._check(self.lib.rt_readback(self.ctx, _ptr(col), _ptr(pos), _ptr(nrm)), "rt_readback")
         return col, pos, nrm
 
+    def get_surfaces(self):
+        """Device pointers (ints) of the context-owned gColor, gPosition, gNormal of the last rt_render."""
+        dc, dp, dn = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self.lib.rt_get_surfaces(self.ctx, ctypes.byref(dc), ctypes.byref(dp), ctypes.byref(dn)), "rt_get_surfaces")
+        return dc.value, dp.value, dn.value
+
     def last_kernel_ms(self):
         ms = ctypes.c_float()
         self._check(self.lib.rt_last_kernel_ms(self.ctx, ctypes.byref(ms)), "rt_last_kernel_ms")
@@ -285,6 +328,22 @@ class RayTracer:
         out = (ctypes.c_uint32 * n.value)()
         self._check(self.lib.rt_debug_tile_costs(self.ctx, out, n.value, ctypes.byref(n), ctypes.byref(tx)), "rt_debug_tile_costs")
         return _np.frombuffer(out, dtype=_np.uint32).reshape(-1, tx.value).copy()
+
+    def ssao(self, d_position, d_normal, d_out, width, height, noise, samples, projection, view, stream=None):
+        """SSAO on the G-buffer surfaces (raw device pointers as ints); noise [nh,nw,4], samples [64,3],
+        matrices [16] are host arrays."""
+        fa = lambda x, n: np.ascontiguousarray(x, dtype=np.float32).reshape(n)
+        noise = np.ascontiguousarray(noise, dtype=np.float32)
+        nh, nw = noise.shape[:2]
+        fp = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        nz, sm, pj, vw = fa(noise, nh * nw * 4), fa(samples, 192), fa(projection, 16), fa(view, 16)
+        self._check(self.lib.rt_ssao(self.ctx, ctypes.c_void_p(d_position), ctypes.c_void_p(d_normal), ctypes.c_void_p(d_out),
+                                     width, height, fp(nz), nw, nh, fp(sm), fp(pj), fp(vw),
+                                     ctypes.c_void_p(stream) if stream else None), "rt_ssao")
+
+    def ssao_blur(self, d_in, d_out, width, height, horizontal=False, stream=None):
+        self._check(self.lib.rt_ssao_blur(self.ctx, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), width, height,
+                                          int(bool(horizontal)), ctypes.c_void_p(stream) if stream else None), "rt_ssao_blur")
 
     def debug_stats(self):
         out = (ctypes.c_uint64 * 4)()

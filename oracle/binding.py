@@ -187,7 +187,9 @@ def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=Fals
         job, out = os.path.join(d, "job.bin"), os.path.join(d, "out.f32")
         with open(job, "wb") as f:
             f.write(b"PFXJOB1\0")
-            f.write(struct.pack("<5i", out_w, out_h, int(out_half), len(textures), len(uniforms)))
+            n_records = sum(4 if (not isinstance(v, (bool, int, float, np.integer, np.floating)) and len(v) == 16) else 1
+                            for _, v in uniforms)
+            f.write(struct.pack("<5i", out_w, out_h, int(out_half), len(textures), n_records))
             for name, arr, opt in textures:
                 arr = np.ascontiguousarray(arr, dtype=np.float32)
                 h, w = arr.shape[:2]
@@ -199,9 +201,12 @@ def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=Fals
                     f.write(struct.pack("<32sii3f", name.encode(), 0, int(val), 0.0, 0.0, 0.0))
                 elif isinstance(val, (float, np.floating)):
                     f.write(struct.pack("<32si4f", name.encode(), 1, float(val), 0.0, 0.0, 0.0))
+                elif len(val) == 16:          # mat4, column-major: four column records
+                    for c in range(4):
+                        f.write(struct.pack("<32si4f", name.encode(), 10 + c, *[float(x) for x in val[4 * c:4 * c + 4]]))
                 else:
-                    v = list(val) + [0.0] * (4 - len(val))
-                    f.write(struct.pack("<32si4f", name.encode(), 2 if len(val) == 2 else 4, *v))
+                    v = [float(x) for x in val] + [0.0] * (4 - len(val))
+                    f.write(struct.pack("<32si4f", name.encode(), {2: 2, 3: 3}.get(len(val), 4), *v))
         subprocess.run([HARNESS, "postfx", vs_path, fs_path, job, out], check=True, capture_output=True)
         return np.fromfile(out, dtype=np.float32).reshape(out_h, out_w, 4)
 
@@ -231,3 +236,34 @@ def bloom(scene, threshold=1.0, strength=0.5, iterations=10, keep=False):
     out = np.zeros((h, w, 4), dtype=np.float32)
     lib.orc_bloom_combine(_ptr(scene), _ptr(a), w, h, strength, _ptr(out))
     return (out, [s.view(np.float16) for s in stages]) if keep else out
+
+
+def ssao(position, normal, noise, samples, projection, view):
+    """CPU restatement of ssaoFs.glsl.  position f32[h,w,4], normal f32/f16[h,w,4], noise f32[nh,nw,4],
+    samples f32[64,3], projection/view f32[16] column-major -> f32[h,w]."""
+    lib = load()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orc_ssao.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, vp, vp, vp]
+    position = np.ascontiguousarray(position, dtype=np.float32)
+    normal = np.ascontiguousarray(np.asarray(normal).astype(np.float32))
+    noise = np.ascontiguousarray(noise, dtype=np.float32)
+    samples = np.ascontiguousarray(samples, dtype=np.float32)
+    projection = np.ascontiguousarray(projection, dtype=np.float32).ravel()
+    view = np.ascontiguousarray(view, dtype=np.float32).ravel()
+    h, w = position.shape[:2]
+    out = np.zeros((h, w), dtype=np.float32)
+    lib.orc_ssao(_ptr(position), _ptr(normal), w, h, _ptr(noise), noise.shape[1], noise.shape[0], _ptr(samples),
+                 _ptr(projection), _ptr(view), _ptr(out))
+    return out
+
+
+def ssao_blur(ao, horizontal=False):
+    """CPU restatement of ssao_blurFs.glsl (one direction).  ao f32[h,w] -> f32[h,w]."""
+    lib = load()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orc_ssao_blur.argtypes = [vp, ci, ci, ci, vp]
+    ao = np.ascontiguousarray(ao, dtype=np.float32)
+    h, w = ao.shape
+    out = np.zeros_like(ao)
+    lib.orc_ssao_blur(_ptr(ao), w, h, int(bool(horizontal)), _ptr(out))
+    return out

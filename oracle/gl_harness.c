@@ -114,6 +114,7 @@ GLF(void, glViewport, GLint, GLint, GLsizei, GLsizei);
 GLF(void, glDrawArrays, GLenum, GLint, GLsizei);
 GLF(void, glClear, GLbitfield);
 GLF(void, glUniform4f, GLint, GLfloat, GLfloat, GLfloat, GLfloat);
+GLF(void, glUniformMatrix4fv, GLint, GLsizei, GLboolean, const GLfloat *);
 
 #define LOAD(name)                                             \
     do {                                                       \
@@ -137,7 +138,7 @@ static void load_gl(void) {
     LOAD(glMemoryBarrier); LOAD(glFinish); LOAD(glGetTexImage);
     LOAD(glGenVertexArrays); LOAD(glBindVertexArray); LOAD(glVertexAttribPointer); LOAD(glEnableVertexAttribArray);
     LOAD(glGenFramebuffers); LOAD(glBindFramebuffer); LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus);
-    LOAD(glViewport); LOAD(glDrawArrays); LOAD(glClear); LOAD(glUniform4f);
+    LOAD(glViewport); LOAD(glDrawArrays); LOAD(glClear); LOAD(glUniform4f); LOAD(glUniformMatrix4fv);
 }
 
 static void gl_check(const char *where) {
@@ -492,7 +493,8 @@ static int mode_probe(int argc, char **argv) {
  *   gl_harness postfx <vs.glsl> <fs.glsl> <job.bin> <out.f32>
  * job.bin ("PFXJOB1"): int32 outW, outH, outFmt (0 rgba32f, 1 rgba16f), nTex, nUni; then per texture
  *   char name[32]; int32 w, h, fmt, filter (0 nearest, 1 linear), wrap (0 repeat, 1 clamp_to_edge); w*h*4 floats;
- * then per uniform  char name[32]; int32 kind (0 int, 1 float, 2 vec2, 4 vec4); float v[4] (ints as float bits).
+ * then per uniform  char name[32]; int32 kind (0 int, 1 float, 2 vec2, 3 vec3, 4 vec4, 10..13 = columns 0..3 of a
+ *   mat4, uploaded when column 3 arrives); float v[4] (ints as float bits).
  * Texture k is bound to unit k and its sampler uniform `name` set to k.  Writes outW*outH*4 floats. */
 typedef struct { char name[32]; int32_t w, h, fmt, filter, wrap; } PfxTex;
 typedef struct { char name[32]; int32_t kind; float v[4]; } PfxUni;
@@ -540,6 +542,12 @@ static int mode_postfx(int argc, char **argv) {
         if (u.kind == 0) p_glUniform1i(loc, iv);
         else if (u.kind == 1) p_glUniform1f(loc, u.v[0]);
         else if (u.kind == 2) p_glUniform2f(loc, u.v[0], u.v[1]);
+        else if (u.kind == 3) p_glUniform3f(loc, u.v[0], u.v[1], u.v[2]);
+        else if (u.kind >= 10 && u.kind <= 13) {
+            static float m[16];
+            memcpy(m + 4 * (u.kind - 10), u.v, 16);
+            if (u.kind == 13) p_glUniformMatrix4fv(loc, 1, GL_FALSE, m);
+        }
         else p_glUniform4f(loc, u.v[0], u.v[1], u.v[2], u.v[3]);
     }
     gl_check("postfx inputs");

@@ -165,3 +165,92 @@ void orc_bloom_combine(const float *scene, const uint16_t *bloom, int W, int H, 
         out[(size_t)k * 4 + 3] = 1.0f;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * SSAO: /root/reference/shader/ssaoFs.glsl:16-46 and ssao_blurFs.glsl:11-29 as driven by
+ * /root/reference/src/AO.cpp:86-117 (kernel samples and the 4x4 rotation texture: AO.cpp:23-51; gPosition
+ * rgba32f / gNormal rgba16f, NEAREST, default wrap = REPEAT: ForwardShadingPipeline.cpp:115-126).
+ * Upstream the pass is dead (its FBOs have no attachments and nothing samples the result); the value
+ * restated here is the float the fragment shader writes.  llvmpipe lowering pinned by probes
+ * (tests/golden/make_golden.py): M*v = ((c0*x + c1*y) + c2*z) + c3*w; projection*view*p is evaluated as
+ * projection*(view*p); dot = (z*z + y*y) + x*x; smoothstep(0,1,x) = t*(t*(3 - 2t)), t = clamp(x,0,1);
+ * NEAREST/REPEAT texel = ifloor(u*size) & (size-1) for power-of-two sizes, itrunc(min(fract(u), 1-ulp)*size)
+ * otherwise.
+ * ------------------------------------------------------------------------------------------- */
+static int nearest_repeat(float u, int size) {
+    if ((size & (size - 1)) == 0) return ((int)floorf(u * (float)size)) & (size - 1);
+    float fr = u - floorf(u);
+    if (!(fr < 1.0f)) fr = 0.99999994f;          /* lp_build_fract_safe */
+    if (!(fr >= 0.0f)) fr = 0.0f;                /* NaN coordinate: fract clamps to 0 */
+    return (int)(fr * (float)size);
+}
+static void nrm3(const float v[3], float o[3]) {
+    float d = (v[2] * v[2] + v[1] * v[1]) + v[0] * v[0];
+    float r = 1.0f / sqrtf(d);
+    o[0] = v[0] * r; o[1] = v[1] * r; o[2] = v[2] * r;
+}
+static void mat4_vec(const float *m, const float v[4], float o[4]) {   /* column-major, w = 1 keeps c3 exact */
+    for (int r = 0; r < 4; r++) o[r] = ((m[r] * v[0] + m[4 + r] * v[1]) + m[8 + r] * v[2]) + m[12 + r] * v[3];
+}
+
+/* position: W*H*4 floats, normal: W*H*4 floats (rgba16f widened), noise: nW*nH*4 floats, samples: 64*3,
+ * projection / view: 16 floats column-major, out: W*H floats.  Row 0 = bottom row. */
+void orc_ssao(const float *position, const float *normal, int W, int H, const float *noise, int nW, int nH,
+              const float *samples, const float *projection, const float *view, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < H; j++) {
+        for (int i = 0; i < W; i++) {
+            const float u = ((float)i + 0.5f) / (float)W, v = ((float)j + 0.5f) / (float)H;
+            const float *fp = position + ((size_t)nearest_repeat(v, H) * W + nearest_repeat(u, W)) * 4;    /* :18 */
+            float n[3], rv[3];
+            nrm3(normal + ((size_t)nearest_repeat(v, H) * W + nearest_repeat(u, W)) * 4, n);             /* :19 */
+            const float nu = u * 200.0f, nv = v * 200.0f;                                                   /* :14,:20 */
+            nrm3(noise + ((size_t)nearest_repeat(nv, nH) * nW + nearest_repeat(nu, nW)) * 4, rv);
+            /* :23-25 */
+            float d = (rv[2] * n[2] + rv[1] * n[1]) + rv[0] * n[0];
+            float t0[3] = {rv[0] - n[0] * d, rv[1] - n[1] * d, rv[2] - n[2] * d}, t[3], b[3];
+            nrm3(t0, t);
+            b[0] = n[1] * t[2] - t[1] * n[2];
+            b[1] = n[2] * t[0] - t[2] * n[0];
+            b[2] = n[0] * t[1] - t[0] * n[1];
+            float occlusion = 0.0f;
+            for (int k = 0; k < 64; k++) {                                                                  /* :29-44 */
+                const float *s = samples + 3 * k;
+                float sp[4];
+                for (int c = 0; c < 3; c++) sp[c] = (t[c] * s[0] + b[c] * s[1]) + n[c] * s[2];              /* TBN * samples[i] */
+                for (int c = 0; c < 3; c++) sp[c] = fp[c] + sp[c] * 0.5f;                                   /* :32 */
+                sp[3] = 1.0f;
+                float vw[4], off[4];
+                mat4_vec(view, sp, vw);
+                mat4_vec(projection, vw, off);                                                              /* :36 */
+                float ox = off[0] / off[3], oy = off[1] / off[3];                                           /* :37 */
+                ox = ox * 0.5f + 0.5f;                                                                      /* :38 */
+                oy = oy * 0.5f + 0.5f;
+                const float sampleDepth = position[((size_t)nearest_repeat(oy, H) * W + nearest_repeat(ox, W)) * 4 + 2];   /* :41 */
+                float x = 0.5f / fabsf(fp[2] - sampleDepth);                                                /* :44 */
+                float tt = fminf(fmaxf(x, 0.0f), 1.0f);
+                float rangeCheck = tt * (tt * (3.0f - 2.0f * tt));
+                occlusion += (sampleDepth >= sp[2] + 0.025f ? 1.0f : 0.0f) * rangeCheck;                    /* :45 */
+            }
+            out[(size_t)j * W + i] = 1.0f - occlusion / 64.0f;                                              /* :47 */
+        }
+    }
+}
+
+/* ssao_blurFs.glsl:11-29 (one direction per pass; ssaoColorBuffer is NEAREST, default wrap REPEAT) */
+void orc_ssao_blur(const float *in, int W, int H, int horizontal, float *out) {
+    const float wgt[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
+    const float tx = 1.0f / (float)W, ty = 1.0f / (float)H;
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < H; j++)
+        for (int i = 0; i < W; i++) {
+            const float u = ((float)i + 0.5f) / (float)W, v = ((float)j + 0.5f) / (float)H;
+            float r = in[(size_t)nearest_repeat(v, H) * W + nearest_repeat(u, W)] * wgt[0];
+            for (int k = 1; k < 5; k++) {
+                const float du = horizontal ? tx * (float)k : 0.0f, dv = horizontal ? 0.0f : ty * (float)k;
+                r += in[(size_t)nearest_repeat(v + dv, H) * W + nearest_repeat(u + du, W)] * wgt[k];
+                r += in[(size_t)nearest_repeat(v - dv, H) * W + nearest_repeat(u - du, W)] * wgt[k];
+            }
+            out[(size_t)j * W + i] = r;
+        }
+}

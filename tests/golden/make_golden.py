@@ -233,6 +233,57 @@ def make_bloom():
     print("  [bloom] written", flush=True)
 
 
+def make_ssao():
+    """SSAO fixture: ssaoFs.glsl and ssao_blurFs.glsl run unmodified on llvmpipe over oracle
+    G-buffers (gPosition rgba32f, gNormal rgba16f, NEAREST / default REPEAT) with the glm view / projection
+    matrices of Camera.h:36-42 and an AO.cpp:23-51-style kernel.  Also the llvmpipe lowering probes the
+    restatement relies on (mat*vec association, projection*view*p = projection*(view*p), smoothstep).
+    Image widths avoid W | 800*(x+0.5): there every pixel centre sits exactly on a rotation-texel boundary
+    (TexCoords * 200 on a 4-texel REPEAT texture) and the reference's own result hangs on interpolation ulps."""
+    R = "/root/reference/shader/"
+    VS = R + "outputVs.glsl"
+    samples, noise = host.ssao_kernel()
+    out = {"samples": samples, "noise": noise}
+    for tag, (cfg, W, H) in {"a": (2, 160, 90), "b": (5, 128, 64), "c": (1, 96, 54)}.items():
+        sc = scenes.make_scene(cfg, host.generate_aabb)
+        p = sc.params(width=W, height=H)
+        _, pos, nrm, _ = O.render(sc, p)
+        nrm = np.ascontiguousarray(nrm).view(np.float16).reshape(H, W, 4)
+        if tag == "c":      # a patch of primary-miss texels: position 0, normal 0 (normalize -> NaN)
+            pos[5:15, 10:30] = 0.0
+            nrm[5:15, 10:30] = 0.0
+        view, proj = host.camera_matrices(p.camPos[:], p.camDir[:], p.camUp[:], p.fovDeg, W / H)
+        uni = [(f"samples[{i}]", tuple(samples[i])) for i in range(64)] + [("projection", tuple(proj)), ("view", tuple(view))]
+        ao = O.run_postfx(VS, R + "ssaoFs.glsl", W, H, [("gPosition", pos, {}), ("gNormal", nrm.astype(np.float32), dict(half=True)),
+                                                         ("texNoise", noise, {})], uni)[..., 0]
+        rep = np.repeat(ao[..., None], 4, axis=2)
+        blur_v = O.run_postfx(VS, R + "ssao_blurFs.glsl", W, H, [("ssaoInput", rep, {})], [("horizontal", 0)])[..., 0]
+        blur_h = O.run_postfx(VS, R + "ssao_blurFs.glsl", W, H, [("ssaoInput", rep, {})], [("horizontal", 1)])[..., 0]
+        out.update({f"{tag}_pos": pos, f"{tag}_nrm": nrm, f"{tag}_view": view, f"{tag}_proj": proj, f"{tag}_ao": ao,
+                    f"{tag}_blur_v": blur_v, f"{tag}_blur_h": blur_h})
+        print(f"  [ssao {tag}] cfg {cfg} {W}x{H}: mean ao {np.nanmean(ao):.4f}, NaN {np.isnan(ao).mean():.4f}", flush=True)
+    # lowering probes (micro-kernels): M*v, A*B*w, smoothstep on random data
+    n = 1024
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((n, 48)) * rng.choice([0.01, 1, 30], (n, 48))).astype(np.float32)
+    glsl = """#version 430
+layout(local_size_x=64) in;
+layout(std430,binding=0) buffer I {float a[];};
+layout(std430,binding=1) buffer Oo {float o[];};
+void main(){ uint g=gl_GlobalInvocationID.x; uint b=g*48u;
+ mat3 M=mat3(vec3(a[b],a[b+1],a[b+2]),vec3(a[b+3],a[b+4],a[b+5]),vec3(a[b+6],a[b+7],a[b+8]));
+ vec3 v=vec3(a[b+9],a[b+10],a[b+11]);
+ mat4 A,B; for(int c=0;c<4;c++){A[c]=vec4(a[b+12+c*4],a[b+13+c*4],a[b+14+c*4],a[b+15+c*4]);B[c]=vec4(a[b+28+c*4],a[b+29+c*4],a[b+30+c*4],a[b+31+c*4]);}
+ vec4 w=vec4(a[b+44],a[b+45],a[b+46],1.0);
+ vec3 r=M*v; vec4 q=A*B*w;
+ float sm=smoothstep(0.0,1.0,0.5/abs(a[b+44]-a[b+45]));
+ uint ob=g*8u; o[ob]=r.x;o[ob+1]=r.y;o[ob+2]=r.z; o[ob+3]=q.x;o[ob+4]=q.y;o[ob+5]=q.z;o[ob+6]=q.w; o[ob+7]=sm; }"""
+    out["probe_in"] = x
+    out["probe_out"] = O.run_probe(glsl, x, np.float32, n * 8, n // 64).reshape(n, 8)
+    np.savez_compressed(os.path.join(OUT, "ssao.npz"), **out)
+    print("  [ssao] written", flush=True)
+
+
 def make_surface_probes():
     """rgba16f imageStore rounding + cubemap sampling through a render-mode job with a tiny
     custom shader is not needed: both are exercised by the c5/nan fixtures.  (Kept as a hook.)"""
@@ -245,7 +296,7 @@ def main():
     args = ap.parse_args()
     if not O.harness_available():
         sys.exit("gl_harness or /root/reference is not available: goldens can only be generated in the build container")
-    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom"]
+    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom", "ssao"]
     for nme in names:
         print(f"== {nme}", flush=True)
         if nme == "probes":
@@ -254,6 +305,8 @@ def main():
             make_taa()
         elif nme == "bloom":
             make_bloom()
+        elif nme == "ssao":
+            make_ssao()
         else:
             make_config(nme, args.skip_fullres)
 
