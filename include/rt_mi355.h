@@ -248,6 +248,16 @@ int rt_ssao_blur(rt_context *ctx, const void *dIn, void *dOut, int width, int he
 int rt_camera_matrices(const float position[3], const float front[3], const float up[3], float fovDeg, float aspect,
                        float view[16], float projection[16]);
 
+/* ---- next row: equirectangular -> cubemap -- ConvertHDRToCubemap (TextureLoader.cpp:118-194) with
+ *      shader/skyboxVs.glsl + skyboxFs.glsl: hEquirectRGB = width*height*3 HOST floats as stbi_loadf returns
+ *      them after the vertical flip (row 0 = bottom); the map is stored as RGB16F (rounded toward zero, as the
+ *      reference's GL does on upload) and
+ *      sampled LINEAR / CLAMP_TO_EDGE into six size x size RGB16F faces (GL face order, the layout
+ *      rt_set_skybox takes).  dFacesOut (device, 6*size*size*3 halfs) may be NULL; install != 0 makes the
+ *      result the context's skybox (what LoadHDRAsCubemap's caller does with the GL texture).  Synchronous. */
+int rt_equirect_to_cubemap(rt_context *ctx, const float *hEquirectRGB, int width, int height, int size,
+                           void *dFacesOut, int install);
+
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);

@@ -566,6 +566,39 @@ int rt_bloom(rt_context *c, const void *dScene, void *dOut, int width, int heigh
 
 const char *rt_last_error(rt_context *c) { return c ? c->err.c_str() : "NULL context"; }
 
+int rt_equirect_to_cubemap(rt_context *c, const float *hEquirectRGB, int width, int height, int size, void *dFacesOut,
+                           int install) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!hEquirectRGB || width <= 0 || height <= 0 || size <= 0) return fail(c, RT_ERR_INVALID_ARG, "bad rt_equirect_to_cubemap arguments");
+    if (!dFacesOut && !install) return fail(c, RT_ERR_INVALID_ARG, "nowhere to put the faces");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t npx = (size_t)width * height, faceBytes = (size_t)6 * size * size * 3 * sizeof(uint16_t);
+    float *dRgb = nullptr;
+    void *dTex = nullptr, *dFaces = nullptr;
+    hipError_t e = hipMalloc((void **)&dRgb, npx * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&dTex, npx * 8);
+    if (e == hipSuccess) e = hipMalloc(&dFaces, faceBytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(dRgb, hEquirectRGB, npx * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rt_launch_equirect_to_cubemap(dRgb, dTex, width, height, size, dFaces, c->stream);
+    if (e == hipSuccess && dFacesOut) e = hipMemcpyAsync(dFacesOut, dFaces, faceBytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dRgb) (void)hipFree(dRgb);
+    if (dTex) (void)hipFree(dTex);
+    if (e != hipSuccess) {
+        if (dFaces) (void)hipFree(dFaces);
+        return fail(c, RT_ERR_HIP, "rt_equirect_to_cubemap", e);
+    }
+    if (install) {
+        if (c->dSky) (void)hipFree(c->dSky);
+        c->dSky = (decltype(c->dSky))dFaces;
+        c->skySize = size;
+    } else {
+        (void)hipFree(dFaces);
+    }
+    return RT_OK;
+}
+
 int rt_ssao(rt_context *c, const void *dPosition, const void *dNormal, void *dOut, int width, int height, const float *hNoise,
             int noiseW, int noiseH, const float *hSamples, const float *hProjection, const float *hView, void *hipStream) {
     if (!c) return RT_ERR_INVALID_ARG;

@@ -55,6 +55,7 @@ hipError_t rt_launch_taa_resolve(const void *current, const void *history, const
 hipError_t rt_launch_ssao(const void *position, const void *normal, void *depthPlane, void *out, int W, int H, const float *noise,
                           int nW, int nH, const float *samples, const float *projection, const float *view, hipStream_t s);
 hipError_t rt_launch_ssao_blur(const void *in, void *out, int W, int H, int horizontal, hipStream_t s);
+hipError_t rt_launch_equirect_to_cubemap(const float *dRgb, void *dTex, int W, int H, int S, void *dFaces, hipStream_t s);
 hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out, int W, int H, float threshold, float strength,
                            int iterations, hipStream_t s);
 hipError_t rt_launch_wire_pack(const void *dColor, const void *dPos, const void *dNormal, void *dWire, size_t nPixels,

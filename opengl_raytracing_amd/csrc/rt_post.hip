@@ -510,3 +510,100 @@ hipError_t rt_launch_ssao_blur(const void *in, void *out, int W, int H, int hori
     else hipLaunchKernelGGL(rt_ssao_blur_kernel<false>, grid, dim3(256), 0, s, (const float *)in, (float *)out, W, H);
     return hipGetLastError();
 }
+
+// =========================================================================================
+// Equirectangular -> cubemap: ConvertHDRToCubemap (TextureLoader.cpp:118-194) with
+// skyboxVs.glsl / skyboxFs.glsl -- six 90-degree captures of a unit cube, per texel
+// texture(equirect, SampleSphericalMap(normalize(localPos))).  Same fp32 expression shapes as
+// oracle/rt_post_oracle.c::orc_equirect_to_cubemap, including Mesa's atan2 / asin lowerings (the oracle is
+// pinned to the shader on llvmpipe with them).  One-off producer of the ray kernel's skybox (6 x 512^2 texels):
+// one lane per face texel, the equirect map is converted to RGB16F once (what GL's upload does, toward zero
+// on the reference's GL) and gathered with 4 bilinear taps; faces are written as packed RGB16F, round toward zero.
+// =========================================================================================
+namespace {
+__device__ __forceinline__ float cm_sign(float x) { return x > 0.0f ? 1.0f : x < 0.0f ? -1.0f : 0.0f; }
+__device__ __forceinline__ float cm_atan(float yx) {
+    const float a = fabsf(yx);
+    const float t = fminf(a, 1.0f) / fmaxf(a, 1.0f);
+    const float x2 = t * t, x3 = x2 * t, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2, x11 = x9 * x2;
+    float p = t * 0.9999793128310355f;
+    p = x3 * -0.3326756418091246f + p;
+    p = x5 * 0.1938924977115610f + p;
+    p = x7 * -0.1173503194786851f + p;
+    p = x9 * 0.0536813784310406f + p;
+    p = x11 * -0.0121323213173444f + p;
+    p = p + (a > 1.0f ? 1.0f : 0.0f) * (p * -2.0f + 1.57079632679489661923f);
+    return p * cm_sign(yx);
+}
+__device__ __forceinline__ float cm_atan2(float y, float x) {
+    const bool flip = 0.0f >= x;
+    const float s = flip ? fabsf(x) : y, t = flip ? y : fabsf(x);
+    const float scale = fabsf(t) >= 1e18f ? 0.25f : 1.0f;
+    const float rcp = 1.0f / (t * scale);
+    const float s_over_t = (s * scale) * rcp;
+    const float tn = fabsf(fabsf(x) == fabsf(y) ? 1.0f : s_over_t);
+    const float arc = (flip ? 1.0f : 0.0f) * 1.57079632679489661923f + cm_atan(tn);
+    return fminf(y, rcp) < 0.0f ? -arc : arc;
+}
+__device__ __forceinline__ float cm_asin(float x) {
+    const float ax = fabsf(x);
+    const float pi4m1 = 0.78539816339744830962f - 1.0f;
+    float t = ax * -0.03102955f + 0.086566724f;
+    t = ax * t + pi4m1;
+    t = ax * t + 1.57079632679489661923f;
+    const float r = 1.57079632679489661923f - sqrtf(1.0f - ax) * t;
+    return cm_sign(x) * r;
+}
+__constant__ float CM_S[6][3] = {{0, 0, -1}, {0, 0, 1}, {1, 0, 0}, {1, 0, 0}, {1, 0, 0}, {-1, 0, 0}};
+__constant__ float CM_U[6][3] = {{0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {0, -1, 0}, {0, -1, 0}};
+__constant__ float CM_F[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+}  // namespace
+
+// f32 RGB -> RGB16F texels (glTexImage2D(GL_RGB16F, GL_FLOAT) upload: the reference's GL rounds toward zero there
+// too -- tests/golden/cubemap.npz's upload probe), padded to 4 halfs
+__global__ __launch_bounds__(256) void rt_equirect_upload_kernel(const float *__restrict__ rgb, uint2 *__restrict__ tex, size_t n) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        tex[k] = make_uint2(cvt_pkrtz_u(rgb[3 * k], rgb[3 * k + 1]), cvt_pkrtz_u(rgb[3 * k + 2], 1.0f));
+    }
+}
+
+__global__ __launch_bounds__(256) void rt_equirect_to_cubemap_kernel(const uint2 *__restrict__ tex, int W, int H, int S,
+                                                                     unsigned short *__restrict__ faces) {
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), j = blockIdx.y * 8 + (threadIdx.x >> 5), f = blockIdx.z;
+    if (i >= S || j >= S) return;
+    const float xn = (((float)i + 0.5f) / (float)S) * 2.0f - 1.0f, yn = (((float)j + 0.5f) / (float)S) * 2.0f - 1.0f;
+    const float px = CM_F[f][0] + xn * CM_S[f][0] + yn * CM_U[f][0], py = CM_F[f][1] + xn * CM_S[f][1] + yn * CM_U[f][1];
+    const float pz = CM_F[f][2] + xn * CM_S[f][2] + yn * CM_U[f][2];
+    const float dd = (pz * pz + py * py) + px * px;
+    const float r = 1.0f / sqrtf(dd);
+    const float dx = px * r, dy = py * r, dz = pz * r;                           // normalize(localPos)
+    float u = cm_atan2(dz, dx), v = cm_asin(dy);                                 // SampleSphericalMap
+    u = u * 0.1591f + 0.5f;
+    v = v * 0.3183f + 0.5f;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;                // LINEAR, CLAMP_TO_EDGE
+    const float fx = floorf(x), fy = floorf(y);
+    const float wx = x - fx, wy = y - fy;
+    const int x0 = min(max((int)fx, 0), W - 1), x1 = min(max((int)fx + 1, 0), W - 1);
+    const int y0 = min(max((int)fy, 0), H - 1), y1 = min(max((int)fy + 1, 0), H - 1);
+    const uint2 t00 = tex[(size_t)y0 * W + x0], t10 = tex[(size_t)y0 * W + x1], t01 = tex[(size_t)y1 * W + x0], t11 = tex[(size_t)y1 * W + x1];
+    auto lerp2 = [&](float a00, float a10, float a01, float a11) -> float {
+        const float a = a00 + wx * (a10 - a00), b = a01 + wx * (a11 - a01);
+        return a + wy * (b - a);
+    };
+    const float cr = lerp2(h2f_u(t00.x), h2f_u(t10.x), h2f_u(t01.x), h2f_u(t11.x));
+    const float cg = lerp2(h2f_u(t00.x >> 16), h2f_u(t10.x >> 16), h2f_u(t01.x >> 16), h2f_u(t11.x >> 16));
+    const float cb = lerp2(h2f_u(t00.y), h2f_u(t10.y), h2f_u(t01.y), h2f_u(t11.y));
+    const unsigned rg = cvt_pkrtz_u(cr, cg), b1 = cvt_pkrtz_u(cb, 1.0f);
+    unsigned short *o = faces + (((size_t)f * S + j) * S + i) * 3;
+    o[0] = (unsigned short)(rg & 0xffffu); o[1] = (unsigned short)(rg >> 16); o[2] = (unsigned short)(b1 & 0xffffu);
+}
+
+hipError_t rt_launch_equirect_to_cubemap(const float *dRgb, void *dTex, int W, int H, int S, void *dFaces, hipStream_t s) {
+    const size_t n = (size_t)W * H;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(rt_equirect_upload_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dRgb, (uint2 *)dTex, n);
+    dim3 grid((S + 31) / 32, (S + 7) / 8, 6);
+    hipLaunchKernelGGL(rt_equirect_to_cubemap_kernel, grid, dim3(256), 0, s, (const uint2 *)dTex, W, H, S, (unsigned short *)dFaces);
+    return hipGetLastError();
+}

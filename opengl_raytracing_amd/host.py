@@ -33,7 +33,7 @@ EXPORTS = [
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
     "rt_count_rays", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
-    "rt_camera_matrices", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_strip_local_rows", "rt_deinterleave",
     "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack",
 ]
 
@@ -89,6 +89,7 @@ def load_library(build_if_missing=True):
     lib.rt_ssao.argtypes = [vp, vp, vp, vp, ci, ci, P(cf), ci, ci, P(cf), P(cf), P(cf), vp]
     lib.rt_ssao_blur.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     lib.rt_camera_matrices.argtypes = [P(cf), P(cf), P(cf), cf, cf, P(cf), P(cf)]
+    lib.rt_equirect_to_cubemap.argtypes = [vp, P(cf), ci, ci, ci, vp, ci]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     lib.rt_wire_bytes.argtypes = [ctypes.c_size_t]
@@ -328,6 +329,15 @@ class RayTracer:
         out = (ctypes.c_uint32 * n.value)()
         self._check(self.lib.rt_debug_tile_costs(self.ctx, out, n.value, ctypes.byref(n), ctypes.byref(tx)), "rt_debug_tile_costs")
         return _np.frombuffer(out, dtype=_np.uint32).reshape(-1, tx.value).copy()
+
+    def equirect_to_cubemap(self, equirect_rgb, size, d_faces_out=None, install=False):
+        """ConvertHDRToCubemap: equirect f32[h,w,3] (row 0 = bottom) -> six RGB16F faces on the device
+        (d_faces_out: raw pointer, 6*size*size*3 halfs) and / or installed as this context's skybox."""
+        e = np.ascontiguousarray(equirect_rgb, dtype=np.float32)
+        h, w = e.shape[:2]
+        self._check(self.lib.rt_equirect_to_cubemap(self.ctx, e.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), w, h, size,
+                                                    ctypes.c_void_p(d_faces_out) if d_faces_out else None, int(bool(install))),
+                    "rt_equirect_to_cubemap")
 
     def ssao(self, d_position, d_normal, d_out, width, height, noise, samples, projection, view, stream=None):
         """SSAO on the G-buffer surfaces (raw device pointers as ints); noise [nh,nw,4], samples [64,3],

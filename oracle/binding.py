@@ -177,7 +177,7 @@ def run_probe(glsl_text, in_array, out_dtype, out_count, groups):
         return np.fromfile(o, dtype=out_dtype)
 
 
-def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=False):
+def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=False, cube=False):
     """One full-screen fragment pass of the reference (gl_harness postfx).
     textures: list of (sampler_name, float32 array [h,w,4], dict(half=False, linear=False, clamp=False));
     uniforms: list of (name, value) with value int | float | tuple.  -> float32 [out_h, out_w, 4]."""
@@ -189,7 +189,7 @@ def run_postfx(vs_path, fs_path, out_w, out_h, textures, uniforms, out_half=Fals
             f.write(b"PFXJOB1\0")
             n_records = sum(4 if (not isinstance(v, (bool, int, float, np.integer, np.floating)) and len(v) == 16) else 1
                             for _, v in uniforms)
-            f.write(struct.pack("<5i", out_w, out_h, int(out_half), len(textures), n_records))
+            f.write(struct.pack("<5i", out_w, out_h, int(out_half) | (2 if cube else 0), len(textures), n_records))
             for name, arr, opt in textures:
                 arr = np.ascontiguousarray(arr, dtype=np.float32)
                 h, w = arr.shape[:2]
@@ -267,3 +267,26 @@ def ssao_blur(ao, horizontal=False):
     out = np.zeros_like(ao)
     lib.orc_ssao_blur(_ptr(ao), w, h, int(bool(horizontal)), _ptr(out))
     return out
+
+
+def equirect_to_cubemap(equirect, size):
+    """CPU restatement of ConvertHDRToCubemap + skyboxFs.glsl.  equirect f32[h,w,3] (fp16-representable values,
+    row 0 = bottom) -> faces f16[6,size,size,3]."""
+    lib = load()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orc_equirect_to_cubemap.argtypes = [vp, ci, ci, ci, vp]
+    equirect = np.ascontiguousarray(equirect, dtype=np.float32)
+    h, w = equirect.shape[:2]
+    faces = np.zeros((6, size, size, 3), dtype=np.uint16)
+    lib.orc_equirect_to_cubemap(_ptr(equirect), w, h, size, _ptr(faces))
+    return faces.view(np.float16)
+
+
+def mesa_atan2_asin(y, x, z):
+    lib = load()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orc_mesa_atan2_asin.argtypes = [vp, vp, vp, ci, vp, vp]
+    y, x, z = (np.ascontiguousarray(a, dtype=np.float32) for a in (y, x, z))
+    a, s = np.zeros_like(y), np.zeros_like(y)
+    lib.orc_mesa_atan2_asin(_ptr(y), _ptr(x), _ptr(z), len(y), _ptr(a), _ptr(s))
+    return a, s

@@ -491,7 +491,8 @@ static int mode_probe(int argc, char **argv) {
 /* Full-screen-quad fragment pass, the way the reference runs its post passes
  * (/root/reference/src/global.cpp:13-39 RenderQuad + an FBO with one colour attachment):
  *   gl_harness postfx <vs.glsl> <fs.glsl> <job.bin> <out.f32>
- * job.bin ("PFXJOB1"): int32 outW, outH, outFmt (0 rgba32f, 1 rgba16f), nTex, nUni; then per texture
+ * job.bin ("PFXJOB1"): int32 outW, outH, outFmt (bit 0: 0 rgba32f, 1 rgba16f; bit 1: draw a unit cube with a vec3
+ *   position attribute instead of the quad -- the capture draw of TextureLoader.cpp:37-115,172-185), nTex, nUni; then per texture
  *   char name[32]; int32 w, h, fmt, filter (0 nearest, 1 linear), wrap (0 repeat, 1 clamp_to_edge); w*h*4 floats;
  * then per uniform  char name[32]; int32 kind (0 int, 1 float, 2 vec2, 3 vec3, 4 vec4, 10..13 = columns 0..3 of a
  *   mat4, uploaded when column 3 arrives); float v[4] (ints as float bits).
@@ -508,7 +509,7 @@ static int mode_postfx(int argc, char **argv) {
     if (!job || joblen < 28 || memcmp(job, "PFXJOB1", 7)) { fprintf(stderr, "bad job\n"); return 2; }
     int32_t hd[5];
     memcpy(hd, job + 8, sizeof hd);
-    const int outW = hd[0], outH = hd[1], outFmt = hd[2], nTex = hd[3], nUni = hd[4];
+    const int outW = hd[0], outH = hd[1], outFmt = hd[2] & 1, cubeGeom = (hd[2] >> 1) & 1, nTex = hd[3], nUni = hd[4];
     if (bootstrap_gl()) { fprintf(stderr, "Mesa swrast unavailable\n"); return EXIT_SKIP; }
     GLuint prog = p_glCreateProgram();
     p_glAttachShader(prog, compile_stage(GL_VERTEX_SHADER, vs));
@@ -566,17 +567,37 @@ static int mode_postfx(int argc, char **argv) {
     static const float quad[] = { /* global.cpp:16-24: position.xy, texcoord.xy */
         -1.0f, 1.0f, 0.0f, 1.0f,  -1.0f, -1.0f, 0.0f, 0.0f,  1.0f, -1.0f, 1.0f, 0.0f,
         -1.0f, 1.0f, 0.0f, 1.0f,   1.0f, -1.0f, 1.0f, 0.0f,  1.0f,  1.0f, 1.0f, 1.0f};
+    /* unit cube, 12 triangles: for each axis a and side s, the face a = s split along one diagonal */
+    float cube[36 * 3];
+    {
+        int n = 0;
+        for (int a = 0; a < 3; a++)
+            for (int sd = -1; sd <= 1; sd += 2) {
+                static const int cu[6] = {-1, 1, 1, 1, -1, -1}, cv[6] = {-1, -1, 1, 1, 1, -1};
+                for (int k = 0; k < 6; k++) {
+                    float p[3];
+                    p[a] = (float)sd; p[(a + 1) % 3] = (float)cu[k]; p[(a + 2) % 3] = (float)cv[k];
+                    cube[n++] = p[0]; cube[n++] = p[1]; cube[n++] = p[2];
+                }
+            }
+    }
     p_glGenVertexArrays(1, &vao);
     p_glGenBuffers(1, &vbo);
     p_glBindVertexArray(vao);
     p_glBindBuffer(GL_ARRAY_BUFFER, vbo);
-    p_glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
-    p_glEnableVertexAttribArray(0);
-    p_glVertexAttribPointer(0, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void *)0);
-    p_glEnableVertexAttribArray(1);
-    p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void *)(2 * sizeof(float)));
+    if (cubeGeom) {
+        p_glBufferData(GL_ARRAY_BUFFER, sizeof cube, cube, GL_STATIC_DRAW);
+        p_glEnableVertexAttribArray(0);
+        p_glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 3 * sizeof(float), (void *)0);
+    } else {
+        p_glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
+        p_glEnableVertexAttribArray(0);
+        p_glVertexAttribPointer(0, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void *)0);
+        p_glEnableVertexAttribArray(1);
+        p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 4 * sizeof(float), (void *)(2 * sizeof(float)));
+    }
     double t0 = now_s();
-    p_glDrawArrays(GL_TRIANGLES, 0, 6);
+    p_glDrawArrays(GL_TRIANGLES, 0, cubeGeom ? 36 : 6);
     p_glFinish();
     double dt = now_s() - t0;
     gl_check("postfx draw");

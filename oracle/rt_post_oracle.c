@@ -254,3 +254,85 @@ void orc_ssao_blur(const float *in, int W, int H, int horizontal, float *out) {
             out[(size_t)j * W + i] = r;
         }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Equirectangular -> cubemap: ConvertHDRToCubemap, /root/reference/src/TextureLoader.cpp:118-194,
+ * with shader/skyboxVs.glsl + skyboxFs.glsl: six 90-degree captures of a unit cube from its centre
+ * (captureViews :160-167), fragment = texture(equirect, SampleSphericalMap(normalize(localPos))), equirect RGB16F
+ * LINEAR / CLAMP_TO_EDGE (:126-132), faces RGB16F (:139-142; render-target stores round toward zero on the
+ * reference's GL).  localPos is the interpolated cube position; at a pixel centre it is f + xn*s + yn*u with
+ * (s, u, f) the right / up / forward vectors of that capture's lookAt (one component +-1, the others +-xn, +-yn).
+ * atan / asin are Mesa's NIR lowerings (nir_builtin_builder.c: nir_atan2 / nir_atan polynomial, build_asin with
+ * p0 = 0.086566724, p1 = -0.03102955), pinned bit for bit on llvmpipe by tests/golden/cubemap.npz's probes
+ * (asin 100 %, atan2 99.95 %, uv 100 % of 8192 vectors); accurate libm versions differ from them by up to 4e-4 rad.
+ * ------------------------------------------------------------------------------------------- */
+static float mesa_atan(float yx) {
+    const float a = fabsf(yx);
+    const float t = fminf(a, 1.0f) / fmaxf(a, 1.0f);
+    const float x2 = t * t, x3 = x2 * t, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2, x11 = x9 * x2;
+    float p = t * 0.9999793128310355f;
+    p = x3 * -0.3326756418091246f + p;
+    p = x5 * 0.1938924977115610f + p;
+    p = x7 * -0.1173503194786851f + p;
+    p = x9 * 0.0536813784310406f + p;
+    p = x11 * -0.0121323213173444f + p;
+    p = p + (a > 1.0f ? 1.0f : 0.0f) * (p * -2.0f + 1.57079632679489661923f);
+    return p * (yx > 0.0f ? 1.0f : yx < 0.0f ? -1.0f : 0.0f);
+}
+static float mesa_atan2(float y, float x) {
+    const int flip = 0.0f >= x;
+    const float s = flip ? fabsf(x) : y, t = flip ? y : fabsf(x);
+    const float scale = fabsf(t) >= 1e18f ? 0.25f : 1.0f;
+    const float rcp = 1.0f / (t * scale);
+    const float s_over_t = (s * scale) * rcp;
+    const float tn = fabsf(fabsf(x) == fabsf(y) ? 1.0f : s_over_t);
+    const float arc = (flip ? 1.0f : 0.0f) * 1.57079632679489661923f + mesa_atan(tn);
+    return fminf(y, rcp) < 0.0f ? -arc : arc;
+}
+static float mesa_asin(float x) {
+    const float ax = fabsf(x);
+    const float pi4m1 = 0.78539816339744830962f - 1.0f;      /* M_PI_4f - 1.0f, in float */
+    float t = ax * -0.03102955f + 0.086566724f;
+    t = ax * t + pi4m1;
+    t = ax * t + 1.57079632679489661923f;
+    const float r = 1.57079632679489661923f - sqrtf(1.0f - ax) * t;
+    return (x > 0.0f ? 1.0f : x < 0.0f ? -1.0f : 0.0f) * r;
+}
+void orc_mesa_atan2_asin(const float *y, const float *x, const float *z, int n, float *outAtan2, float *outAsin) {
+    for (int i = 0; i < n; i++) { outAtan2[i] = mesa_atan2(y[i], x[i]); outAsin[i] = mesa_asin(z[i]); }
+}
+
+/* equirect: W*H*3 floats as stbi_loadf returns them (row 0 = bottom after its flip); the RGB16F texture the
+ * reference uploads them into stores them rounded toward zero on its GL (pinned by tests/golden/cubemap.npz's
+ * upload probe); faces: 6*S*S*3 halfs, GL face order +X,-X,+Y,-Y,+Z,-Z, row 0 = t = 0. */
+void orc_equirect_to_cubemap(const float *equirect, int W, int H, int S, uint16_t *faces) {
+    static const float FS[6][3] = {{0, 0, -1}, {0, 0, 1}, {1, 0, 0}, {1, 0, 0}, {1, 0, 0}, {-1, 0, 0}};
+    static const float FU[6][3] = {{0, -1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {0, -1, 0}, {0, -1, 0}};
+    static const float FF[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int f = 0; f < 6; f++)
+        for (int j = 0; j < S; j++)
+            for (int i = 0; i < S; i++) {
+                const float xn = (((float)i + 0.5f) / (float)S) * 2.0f - 1.0f, yn = (((float)j + 0.5f) / (float)S) * 2.0f - 1.0f;
+                float p[3], d[3];
+                for (int c = 0; c < 3; c++) p[c] = FF[f][c] + xn * FS[f][c] + yn * FU[f][c];
+                nrm3(p, d);                                                     /* skyboxFs.glsl:16 */
+                float u = mesa_atan2(d[2], d[0]), v = mesa_asin(d[1]);          /* :9 */
+                u = u * 0.1591f + 0.5f;                                         /* :10-11 */
+                v = v * 0.3183f + 0.5f;
+                /* LINEAR, CLAMP_TO_EDGE */
+                const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+                const float fx = floorf(x), fy = floorf(y);
+                const float wx = x - fx, wy = y - fy;
+                int x0 = (int)fx, x1 = x0 + 1, y0 = (int)fy, y1 = y0 + 1;
+                x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+                y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+                uint16_t *o = faces + (((size_t)f * S + j) * S + i) * 3;
+                for (int c = 0; c < 3; c++) {
+                    const float t00 = h2f(f2h_rt(equirect[((size_t)y0 * W + x0) * 3 + c])), t10 = h2f(f2h_rt(equirect[((size_t)y0 * W + x1) * 3 + c]));
+                    const float t01 = h2f(f2h_rt(equirect[((size_t)y1 * W + x0) * 3 + c])), t11 = h2f(f2h_rt(equirect[((size_t)y1 * W + x1) * 3 + c]));
+                    const float a = t00 + wx * (t10 - t00), b = t01 + wx * (t11 - t01);
+                    o[c] = f2h_rt(a + wy * (b - a));
+                }
+            }
+}

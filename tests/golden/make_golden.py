@@ -284,6 +284,84 @@ void main(){ uint g=gl_GlobalInvocationID.x; uint b=g*48u;
     print("  [ssao] written", flush=True)
 
 
+def _look_at(eye, center, up):
+    """glm::lookAtRH, column-major float32[16]."""
+    f32 = np.float32
+    eye, center, up = (np.asarray(a, f32) for a in (eye, center, up))
+    nrm = lambda v: (v * (f32(1) / np.sqrt(np.dot(v, v).astype(f32)))).astype(f32)
+    f = nrm(center - eye)
+    s_ = nrm(np.cross(f, up).astype(f32))
+    u = np.cross(s_, f).astype(f32)
+    m = np.zeros((4, 4), f32)
+    m[0][0], m[1][0], m[2][0] = s_
+    m[0][1], m[1][1], m[2][1] = u
+    m[0][2], m[1][2], m[2][2] = -f
+    m[3][0], m[3][1], m[3][2], m[3][3] = -np.dot(s_, eye), -np.dot(u, eye), np.dot(f, eye), 1
+    return m.ravel()
+
+
+def _perspective(fovy, aspect, zn, zf):
+    f32 = np.float32
+    t = f32(np.tan(f32(fovy) / f32(2)))
+    m = np.zeros((4, 4), f32)
+    m[0][0], m[1][1] = f32(1) / (f32(aspect) * t), f32(1) / t
+    m[2][2], m[2][3] = -(f32(zf) + f32(zn)) / (f32(zf) - f32(zn)), -1
+    m[3][2] = -(f32(2) * f32(zf) * f32(zn)) / (f32(zf) - f32(zn))
+    return m.ravel()
+
+
+def make_cubemap():
+    """Equirect -> cubemap fixture: skyboxVs.glsl + skyboxFs.glsl drawn over a unit cube with
+    the six captureViews and the 90-degree captureProjection of TextureLoader.cpp:158-167, on a synthetic HDR
+    panorama whose texels are fp16-representable (so the RGB16F upload is exact).  Face sizes are even: with an
+    odd size the centre column of the -X face sits exactly on the atan seam (z = +-0) and the reference's own
+    texels there flip between the panorama's two edges.  Plus probes of llvmpipe's atan(y,x) / asin lowering and
+    of the float -> RGB16F upload rounding."""
+    R = "/root/reference/shader/"
+    f32 = np.float32
+    W, H = 64, 32
+    rng = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:H, 0:W]
+    eqr = np.stack([1 + np.sin(xx / 5.0) + yy / 8.0, 2 + np.cos(yy / 3.0) * np.sin(xx / 7.0), (xx + yy) % 7 / 2.0], -1)
+    eqr = ((eqr + rng.uniform(0, 0.3, (H, W, 3))) ** 2).astype(np.float16).astype(f32)
+    tex = np.concatenate([eqr, np.ones((H, W, 1), f32)], -1)
+    proj = _perspective(np.radians(f32(90.0)), 1.0, 0.1, 10.0)
+    views = [((1, 0, 0), (0, -1, 0)), ((-1, 0, 0), (0, -1, 0)), ((0, 1, 0), (0, 0, 1)), ((0, -1, 0), (0, 0, -1)),
+             ((0, 0, 1), (0, -1, 0)), ((0, 0, -1), (0, -1, 0))]
+    out = {"equirect": eqr}
+    for S in (32, 20, 128):
+        faces = []
+        for tg, up in views:
+            ref = O.run_postfx(R + "skyboxVs.glsl", R + "skyboxFs.glsl", S, S,
+                               [("equirectangularMap", tex, dict(half=True, linear=True, clamp=True))],
+                               [("projection", tuple(proj)), ("view", tuple(_look_at((0, 0, 0), tg, up)))], out_half=True, cube=True)
+            assert (ref[..., 3] == 1).all()
+            faces.append(ref[..., :3].astype(np.float16))      # exact: the target is rgba16f
+        out[f"faces_{S}"] = np.stack(faces)
+        print(f"  [cubemap] S={S} done", flush=True)
+    n = 4096
+    v = rng.standard_normal((n, 3)).astype(f32)
+    v[:48] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [1, 1, 0], [1, 0, 1]] * 6, f32)
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(f32)
+    glsl = """#version 430
+layout(local_size_x=64) in;
+layout(std430,binding=0) buffer I {float a[];};
+layout(std430,binding=1) buffer Oo {float o[];};
+void main(){ uint g=gl_GlobalInvocationID.x; vec3 v=vec3(a[g*3u],a[g*3u+1u],a[g*3u+2u]);
+ o[g*4u]=atan(v.z,v.x); o[g*4u+1u]=asin(v.y); vec2 uv=vec2(atan(v.z,v.x),asin(v.y)); uv*=vec2(0.1591,0.3183); uv+=0.5; o[g*4u+2u]=uv.x; o[g*4u+3u]=uv.y; }"""
+    out["probe_v"] = v
+    out["probe_out"] = O.run_probe(glsl, v, np.float32, n * 4, n // 64).reshape(n, 4)
+    # upload rounding: arbitrary floats into an RGBA16F texture, read back texel-exact through the extract shader
+    # (threshold -1: brightness_extractFS.glsl passes the colour through)
+    up = np.abs(rng.standard_normal((16, 32, 4))).astype(f32) * rng.choice([1e-3, 1.0, 50.0], (16, 32, 1)).astype(f32)
+    up[..., 3] = 1
+    out["upload_in"] = up
+    out["upload_out"] = O.run_postfx(R + "outputVs.glsl", R + "brightness_extractFS.glsl", 32, 16,
+                                     [("hdrTexture", up, dict(half=True, linear=True))], [("threshold", -1.0)])
+    np.savez_compressed(os.path.join(OUT, "cubemap.npz"), **out)
+    print("  [cubemap] written", flush=True)
+
+
 def make_surface_probes():
     """rgba16f imageStore rounding + cubemap sampling through a render-mode job with a tiny
     custom shader is not needed: both are exercised by the c5/nan fixtures.  (Kept as a hook.)"""
@@ -296,7 +374,7 @@ def main():
     args = ap.parse_args()
     if not O.harness_available():
         sys.exit("gl_harness or /root/reference is not available: goldens can only be generated in the build container")
-    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom", "ssao"]
+    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom", "ssao", "cubemap"]
     for nme in names:
         print(f"== {nme}", flush=True)
         if nme == "probes":
@@ -307,6 +385,8 @@ def main():
             make_bloom()
         elif nme == "ssao":
             make_ssao()
+        elif nme == "cubemap":
+            make_cubemap()
         else:
             make_config(nme, args.skip_fullres)
 
