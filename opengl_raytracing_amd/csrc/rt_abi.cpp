@@ -227,9 +227,17 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         }
         // The sort runs on the context's own stream, beside the frames; its order is adopted by the first launch
         // issued after it has completed, so no render stream ever waits for it.
-        if (c->sortPending && hipEventQuery(c->evSort) == hipSuccess) {
-            c->fbCur = c->fbNext;
-            c->sortPending = false;
+        if (c->sortPending) {
+            if (hipEventQuery(c->evSort) == hipSuccess) {
+                c->fbCur = c->fbNext;
+                c->sortPending = false;
+            } else if (c->fbCur < 0) {
+                // no order at all yet (second frame of a geometry, host running ahead of the device): take the
+                // first order as soon as the device has it -- this stream waits for the sort, nothing else does
+                HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
+                c->fbCur = c->fbNext;
+                c->sortPending = false;
+            }
         }
         const bool same = c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt;
         if (!same) {                           // new geometry: nobody may still be using the old costs / order
