@@ -258,6 +258,31 @@ int rt_camera_matrices(const float position[3], const float front[3], const floa
 int rt_equirect_to_cubemap(rt_context *ctx, const float *hEquirectRGB, int width, int height, int size,
                            void *dFacesOut, int install);
 
+/* ---- the caller of the path: one iteration of ForwardShadingPipline::Render()'s GPU work
+ *      (ForwardShadingPipeline.cpp:155-260) in one call, on the context's own surfaces and stream:
+ *        ray trace (:155-182)  ->  AO (:185-187, if enableAO)  ->  bloom: extract, blur passes, combine into the
+ *        image the reference draws to the default framebuffer (:189-228)  ->  TAA resolve into
+ *        historyTex[frameCount % 2] from historyTex[1 - frameCount % 2] (:231-258, if enableTAA).
+ *      p->frameCount plays the reference's static frameCount (:141-142): it selects the history slot and the
+ *      TAA jitter and is the shader's frameCount uniform; like the reference, the caller advances it only on
+ *      frames with TAA enabled (:254).  History surfaces start as zeros.  dDisplay (device, width*height
+ *      rgba32f) receives the bloom-combined image; may be NULL.  Asynchronous on the context's stream;
+ *      rt_frame_surfaces returns the context-owned results (valid until the next size change). */
+typedef struct rt_frame_desc {
+    int32_t enableAO, enableTAA;
+    float taaBlendFactor;            /* imguiManager.GetTAABlendFactor() */
+    float bloomThreshold;            /* 1.0  (:197) */
+    float bloomStrength;             /* 0.5  (:223) */
+    int32_t bloomIterations;         /* 10   (:212) */
+    const float *aoSamples;          /* 64 x 3 host floats (AO.cpp:23-36); required when enableAO */
+    const float *aoNoise;            /* 4 x 4 x 4 host floats (AO.cpp:38-51) */
+    float camYawPitchUnused[2];      /* reserved, zero */
+} rt_frame_desc;
+int rt_frame(rt_context *ctx, const rt_params *p, const rt_frame_desc *desc, void *dDisplay);
+/* dAO = blurred AO (floats), dHistory = the history slot the last rt_frame wrote (rgba32f); NULL when that
+ * pass has not run. */
+int rt_frame_surfaces(rt_context *ctx, void **dColor, void **dPosition, void **dNormal, void **dAO, void **dHistory);
+
 /* ---- multi-GPU strip helpers */
 /* Number of local rows a rank owns for interleaved strips. */
 int rt_strip_local_rows(int height, int stripRows, int stripCount, int stripIndex);
@@ -303,6 +328,7 @@ int rt_wire_unpack(rt_context *ctx, const void *dWire, size_t rankStrideBytes, s
 #define RT_SA(c, m) _Static_assert(c, m)
 #endif
 RT_SA(sizeof(rt_material) == 80, "Material is 80 B");
+RT_SA(sizeof(rt_frame_desc) == 32 + 2 * sizeof(void *), "rt_frame_desc layout");
 RT_SA(sizeof(rt_object) == RT_OBJECT_STRIDE, "Object stride is 176 B");
 RT_SA(sizeof(rt_light) == RT_LIGHT_STRIDE, "Light stride is 96 B");
 RT_SA(offsetof(rt_object, position) == 16 && offsetof(rt_object, radius) == 28, "Object.position/radius");

@@ -60,6 +60,13 @@ struct rt_context {
     void *dBloom[2] = {nullptr, nullptr};      // rgba16f ping-pong targets of rt_bloom
     float *dSsaoDepth = nullptr;               // gPosition.z plane of rt_ssao
     size_t capSsaoPx = 0;
+    // rt_frame: AO result (raw, blurred), TAA history ping-pong, bloom-combined image when the caller passes none
+    float *dFrameAO[2] = {nullptr, nullptr};
+    float4 *dHistory[2] = {nullptr, nullptr};
+    float4 *dFrameDisplay = nullptr;
+    size_t capFramePx = 0;
+    int frameW = 0, frameH = 0, lastHistory = -1;
+    bool frameAOValid = false;
     size_t capBloomPx = 0;
     bool feedback = true;
     std::string err;
@@ -316,7 +323,7 @@ int rt_destroy(rt_context *c) {
             (void)hipEventDestroy(c->fbStreams[i].last);
         }
     void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
-                    c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1], c->dSsaoDepth};
+                    c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1], c->dSsaoDepth, c->dFrameAO[0], c->dFrameAO[1], c->dHistory[0], c->dHistory[1], c->dFrameDisplay};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -636,6 +643,80 @@ int rt_ssao_blur(rt_context *c, const void *dIn, void *dOut, int width, int heig
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
     HIP_TRY(c, rt_launch_ssao_blur(dIn, dOut, width, height, horizontal, s));
+    return RT_OK;
+}
+
+int rt_frame(rt_context *c, const rt_params *p, const rt_frame_desc *d, void *dDisplay) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!d) return fail(c, RT_ERR_INVALID_ARG, "frame description is NULL");
+    if (d->enableAO && (!d->aoSamples || !d->aoNoise)) return fail(c, RT_ERR_INVALID_ARG, "AO needs its kernel samples and rotation texture");
+    if (d->bloomIterations < 0) return fail(c, RT_ERR_INVALID_ARG, "bloomIterations < 0");
+    int rc = validate_params(c, p);
+    if (rc) return rc;
+    if (p->x0 != 0 || p->y0 != 0 || p->regionW != p->width || p->regionH != p->height || p->stripCycleRows != 0 || p->stripCount != 1)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_frame renders the whole image on one device");
+    const int W = p->width, H = p->height;
+    const size_t npx = (size_t)W * H;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (npx > c->capFramePx) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        void **bufs[] = {(void **)&c->dFrameAO[0], (void **)&c->dFrameAO[1], (void **)&c->dHistory[0], (void **)&c->dHistory[1],
+                         (void **)&c->dFrameDisplay};
+        for (void **b : bufs) {
+            if (*b) HIP_TRY(c, hipFree(*b));
+            *b = nullptr;
+        }
+        c->capFramePx = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->dFrameAO[0], npx * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void **)&c->dFrameAO[1], npx * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void **)&c->dHistory[0], npx * sizeof(float4)));
+        HIP_TRY(c, hipMalloc((void **)&c->dHistory[1], npx * sizeof(float4)));
+        HIP_TRY(c, hipMalloc((void **)&c->dFrameDisplay, npx * sizeof(float4)));
+        c->capFramePx = npx;
+        c->frameW = c->frameH = 0;
+    }
+    if (c->frameW != W || c->frameH != H) {      // new size: the history starts as zeros (glTexImage2D(..., nullptr))
+        HIP_TRY(c, hipMemsetAsync(c->dHistory[0], 0, npx * sizeof(float4), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->dHistory[1], 0, npx * sizeof(float4), c->stream));
+        c->frameW = W;
+        c->frameH = H;
+        c->lastHistory = -1;
+    }
+    rc = rt_render(c, p);                                                   // :155-182
+    if (rc) return rc;
+    c->frameAOValid = false;
+    if (d->enableAO) {                                                      // :185-187, AO.cpp:86-117
+        float view[16], proj[16];
+        rc = rt_camera_matrices(p->camPos, p->camDir, p->camUp, p->fovDeg, (float)W / (float)H, view, proj);
+        if (rc) return fail(c, rc, "rt_camera_matrices");
+        rc = rt_ssao(c, c->dPos, c->dNormal, c->dFrameAO[0], W, H, d->aoNoise, 4, 4, d->aoSamples, proj, view, nullptr);
+        if (rc) return rc;
+        rc = rt_ssao_blur(c, c->dFrameAO[0], c->dFrameAO[1], W, H, 0, nullptr);   // `horizontal` is never set upstream
+        if (rc) return rc;
+        c->frameAOValid = true;
+    }
+    rc = rt_bloom(c, c->dColor, dDisplay ? dDisplay : (void *)c->dFrameDisplay, W, H, d->bloomThreshold, d->bloomStrength,
+                  d->bloomIterations, nullptr);                             // :189-228
+    if (rc) return rc;
+    if (d->enableTAA) {                                                     // :231-258
+        const int cur = ((p->frameCount % 2) + 2) % 2;
+        float jx, jy;
+        rc = rt_taa_jitter(p->frameCount, W, H, &jx, &jy);
+        if (rc) return fail(c, rc, "rt_taa_jitter");
+        rc = rt_taa_resolve(c, c->dColor, c->dHistory[1 - cur], c->dNormal, c->dHistory[cur], W, H, d->taaBlendFactor, jx, jy, nullptr);
+        if (rc) return rc;
+        c->lastHistory = cur;
+    }
+    return RT_OK;
+}
+
+int rt_frame_surfaces(rt_context *c, void **dColor, void **dPosition, void **dNormal, void **dAO, void **dHistory) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (dColor) *dColor = c->dColor;
+    if (dPosition) *dPosition = c->dPos;
+    if (dNormal) *dNormal = c->dNormal;
+    if (dAO) *dAO = c->frameAOValid ? c->dFrameAO[1] : nullptr;
+    if (dHistory) *dHistory = c->lastHistory >= 0 ? c->dHistory[c->lastHistory] : nullptr;
     return RT_OK;
 }
 

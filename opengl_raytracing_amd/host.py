@@ -33,9 +33,19 @@ EXPORTS = [
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
     "rt_count_rays", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
-    "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_strip_local_rows", "rt_deinterleave",
+    "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_frame", "rt_frame_surfaces", "rt_strip_local_rows", "rt_deinterleave",
     "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack",
 ]
+
+
+
+class RtFrameDesc(ctypes.Structure):
+    """``rt_frame_desc`` of include/rt_mi355.h."""
+    _fields_ = [("enableAO", ctypes.c_int32), ("enableTAA", ctypes.c_int32), ("taaBlendFactor", ctypes.c_float),
+                ("bloomThreshold", ctypes.c_float), ("bloomStrength", ctypes.c_float), ("bloomIterations", ctypes.c_int32),
+                ("aoSamples", ctypes.POINTER(ctypes.c_float)), ("aoNoise", ctypes.POINTER(ctypes.c_float)),
+                ("reserved", ctypes.c_float * 2)]
+
 
 RT_OK = 0
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARG", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP",
@@ -90,6 +100,8 @@ def load_library(build_if_missing=True):
     lib.rt_ssao_blur.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     lib.rt_camera_matrices.argtypes = [P(cf), P(cf), P(cf), cf, cf, P(cf), P(cf)]
     lib.rt_equirect_to_cubemap.argtypes = [vp, P(cf), ci, ci, ci, vp, ci]
+    lib.rt_frame.argtypes = [vp, P(L.RtParams), P(RtFrameDesc), vp]
+    lib.rt_frame_surfaces.argtypes = [vp, P(vp), P(vp), P(vp), P(vp), P(vp)]
     lib.rt_strip_local_rows.argtypes = [ci, ci, ci, ci]
     lib.rt_deinterleave.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_size_t, vp]
     lib.rt_wire_bytes.argtypes = [ctypes.c_size_t]
@@ -329,6 +341,29 @@ class RayTracer:
         out = (ctypes.c_uint32 * n.value)()
         self._check(self.lib.rt_debug_tile_costs(self.ctx, out, n.value, ctypes.byref(n), ctypes.byref(tx)), "rt_debug_tile_costs")
         return _np.frombuffer(out, dtype=_np.uint32).reshape(-1, tx.value).copy()
+
+    def frame(self, params, enable_ao=True, enable_taa=True, taa_blend=0.1, bloom_threshold=1.0, bloom_strength=0.5,
+              bloom_iterations=10, ao_samples=None, ao_noise=None, d_display=None):
+        """One iteration of the reference's Render() GPU work (ray trace, AO, bloom, TAA) on the context's surfaces."""
+        d = RtFrameDesc()
+        d.enableAO, d.enableTAA, d.taaBlendFactor = int(bool(enable_ao)), int(bool(enable_taa)), taa_blend
+        d.bloomThreshold, d.bloomStrength, d.bloomIterations = bloom_threshold, bloom_strength, bloom_iterations
+        keep = []
+        if enable_ao:
+            if ao_samples is None or ao_noise is None:
+                ao_samples, ao_noise = ssao_kernel()
+            for name, arr, n in (("aoSamples", ao_samples, 192), ("aoNoise", ao_noise, 64)):
+                a = np.ascontiguousarray(arr, dtype=np.float32).reshape(n)
+                keep.append(a)
+                setattr(d, name, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        self._check(self.lib.rt_frame(self.ctx, ctypes.byref(params), ctypes.byref(d),
+                                      ctypes.c_void_p(d_display) if d_display else None), "rt_frame")
+
+    def frame_surfaces(self):
+        """(dColor, dPosition, dNormal, dAO, dHistory) device pointers (ints or None) after rt_frame."""
+        ptrs = [ctypes.c_void_p() for _ in range(5)]
+        self._check(self.lib.rt_frame_surfaces(self.ctx, *[ctypes.byref(q) for q in ptrs]), "rt_frame_surfaces")
+        return tuple(q.value for q in ptrs)
 
     def equirect_to_cubemap(self, equirect_rgb, size, d_faces_out=None, install=False):
         """ConvertHDRToCubemap: equirect f32[h,w,3] (row 0 = bottom) -> six RGB16F faces on the device
