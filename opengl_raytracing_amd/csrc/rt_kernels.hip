@@ -672,7 +672,9 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 // Two instantiations: 64-thread workgroups (one wave, 8x8 tile; finer-grained scheduling, no
 // intra-group imbalance, 112 VGPRs / 4 waves per SIMD with NO scratch) for small scenes, where
 // staging the compiled scene per wave is cheap, and 256-thread workgroups (16x16 tile, staging
-// amortised over four waves, 5 waves per SIMD) for larger ones.  Measured in DESIGN.md.
+// amortised over four waves, 5 waves per SIMD = 96 VGPRs + 168 B/lane of scratch) for larger ones.
+// Measured at full size (C4 4K / C5 8K): 6 waves (80 VGPRs, 240 B scratch) 12.0 / 108.1 ms, 5 waves 11.6 / 103.4,
+// 4 waves (128 VGPRs, 24 B) 12.5 / 101.2; the scratch shows up as HBM traffic (profiles/traffic.json c4, c5).
 #ifndef RT_PK_WAVES_SMALL
 #define RT_PK_WAVES_SMALL 4
 #endif
