@@ -679,7 +679,7 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #define RT_PK_WAVES_SMALL 4
 #endif
 #ifndef RT_PK_WAVES_LARGE
-#define RT_PK_WAVES_LARGE 6
+#define RT_PK_WAVES_LARGE 5
 #endif
 #ifndef RT_PK_SMALL_SCENE
 #define RT_PK_SMALL_SCENE 32    // objects: at or below, use the one-wave workgroup
