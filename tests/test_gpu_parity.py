@@ -365,3 +365,27 @@ def test_cpp_host_example_matches_python_path(host, oracle, tmp_path):
 
     assert out["rays"] == rays
     assert out["color"] == fnv(col) and out["position"] == fnv(pos) and out["normal"] == fnv(nrm)
+
+
+def test_frames_in_flight_on_several_streams(tracer, host):
+    """bench.py's N > 1 pipeline keeps several frames in flight on separate render streams while the tile-order
+    feedback re-sorts beside them (double-buffered order, sort on the context's stream).  Every frame must still
+    cover every tile exactly once: buffers are zeroed before each launch, so a torn order would leave holes."""
+    import torch
+    sc = scenes.make_scene(2, host.generate_aabb)
+    p = sc.params(width=640, height=360)
+    tracer.load(sc)
+    ref = render_gpu(tracer, sc, p)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bufs = [(torch.empty((360, 640, 4), dtype=torch.float32, device="cuda"), torch.empty((360, 640, 4), dtype=torch.float32, device="cuda"),
+             torch.empty((360, 640, 4), dtype=torch.float16, device="cuda")) for _ in range(3)]
+    for k in range(150):
+        s, (c, q, n) = streams[k % 3], bufs[k % 3]
+        with torch.cuda.stream(s):
+            c.zero_(); q.zero_(); n.zero_()
+        tracer.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=s.cuda_stream)
+        if k % 37 == 36 or k >= 147:
+            torch.cuda.synchronize()
+            for got, want in zip((c, q, n), ref):
+                assert bits_equal(got.cpu().numpy(), want), f"frame {k}"
+    torch.cuda.synchronize()
