@@ -235,7 +235,9 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         // The sort runs on the context's own stream, beside the frames; its order is adopted by the first launch
         // issued after it has completed, so no render stream ever waits for it.
         if (c->sortPending) {
-            if (hipEventQuery(c->evSort) == hipSuccess) {
+            const hipError_t q = hipEventQuery(c->evSort);
+            (void)hipGetLastError();           // hipErrorNotReady is an answer, not an error to find later
+            if (q == hipSuccess) {
                 c->fbCur = c->fbNext;
                 c->sortPending = false;
             } else if (c->fbCur < 0) {

@@ -120,6 +120,11 @@ struct SceneLds {
     float *park = nullptr;                 // per-thread LDS parking area, 9 floats x BLOCK_THREADS (packet kernel)
     int tileX = 0, tileY = 0;              // this workgroup's tile (packet kernel; wave-uniform)
     int lgtF4Base = 0, haltonFloatBase = 0;   // offsets of the light / Halton sections (float4 / float units)
+    // Compact staging (packet kernel, scenes too large to keep whole in LDS at full occupancy): LDS holds only
+    // the two bounds float4 of every object (stride 2); shape / material records read per lane by hit index come
+    // from the global copy.  hotStride = float4 stride of `hot`, matF4Base = material section in `global`.
+    bool compact = false;
+    int hotStride = RT_HOT_F4, matF4Base = 0;
 };
 
 // haltonSequence (raytracingCs.glsl:278-288); used by the scene compiler and as the
@@ -684,18 +689,29 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #ifndef RT_PK_SMALL_SCENE
 #define RT_PK_SMALL_SCENE 32    // objects: at or below, use the one-wave workgroup
 #endif
-template <bool COUNT, int BT>
+#ifndef RT_PK_COMPACT_SCENE
+#define RT_PK_COMPACT_SCENE 144  // objects: above (5 workgroups x (160 B/object + parking) no longer fit a CU), stage only the AABBs in LDS
+#endif
+template <bool COUNT, int BT, bool COMPACT>
 __global__ __launch_bounds__(BT, (BT == 64 ? RT_PK_WAVES_SMALL : RT_PK_WAVES_LARGE))
 void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
                              float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
                              unsigned long long *rayCounter) {
     extern __shared__ float4 lds[];
-    const int nF4 = f.nObj * (RT_HOT_F4 + RT_MAT_F4) + f.nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
-    for (int i = threadIdx.x; i < nF4; i += BT) lds[i] = dsc.compiled[i];
+    const int nAll = f.nObj * (RT_HOT_F4 + RT_MAT_F4) + f.nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
+    const int nF4 = COMPACT ? f.nObj * 2 : nAll;          // float4 staged in LDS
+    if (COMPACT) {
+        for (int i = threadIdx.x; i < nF4; i += BT) lds[i] = dsc.compiled[(i >> 1) * RT_HOT_F4 + (i & 1)];
+    } else {
+        for (int i = threadIdx.x; i < nF4; i += BT) lds[i] = dsc.compiled[i];
+    }
     __syncthreads();
     SceneLds sc;
+    sc.compact = COMPACT;
+    sc.hotStride = COMPACT ? 2 : RT_HOT_F4;
+    sc.matF4Base = f.nObj * RT_HOT_F4;
     sc.hot = lds;
-    sc.mat = sc.hot + f.nObj * RT_HOT_F4;
+    sc.mat = sc.hot + f.nObj * RT_HOT_F4;                  // (not staged, never read through LDS, when COMPACT)
     sc.lgt = sc.mat + f.nObj * RT_MAT_F4;
     sc.halton2 = (const float *)(sc.lgt + f.nLt * RT_LGT_F4);
     sc.halton3 = sc.halton2 + RT_HALTON_N;
@@ -703,7 +719,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     sc.global = dsc.compiled;
     sc.lgtF4Base = f.nObj * (RT_HOT_F4 + RT_MAT_F4);
     sc.haltonFloatBase = (sc.lgtF4Base + f.nLt * RT_LGT_F4) * 4;
-    sc.park = (float *)(lds + nF4 + 1);      // after the scene and the 16-byte counter slot
+    sc.park = (float *)(lds + nF4 + 1);      // after the staged scene and the 16-byte counter slot
 
     // tile of this workgroup: longest-first order from the previous frame's measured costs, if any
     constexpr int TILE_ = (BT == 256) ? 16 : 8;
@@ -827,11 +843,15 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
         dim3 grid(nTiles);
         const size_t ldsBytes = sceneBytes + 9 * bt * sizeof(float);                    // + the parking area
         if (small) {
-            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        } else if (f.nObj > RT_PK_COMPACT_SCENE) {
+            const size_t compactBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) + 9 * bt * sizeof(float);
+            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         } else {
-            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 256>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 256>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         }
     } else {
         dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
