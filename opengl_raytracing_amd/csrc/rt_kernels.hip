@@ -674,12 +674,14 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 // =========================================================================================
 // Render kernel, wavefront-packet variant (rt_packet.inc): same staging and lane->pixel map.
 // =========================================================================================
-// Two instantiations: 64-thread workgroups (one wave, 8x8 tile; finer-grained scheduling, no
-// intra-group imbalance, 112 VGPRs / 4 waves per SIMD with NO scratch) for small scenes, where
-// staging the compiled scene per wave is cheap, and 256-thread workgroups (16x16 tile, staging
-// amortised over four waves, 5 waves per SIMD = 96 VGPRs + 168 B/lane of scratch) for larger ones.
-// Measured at full size (C4 4K / C5 8K): 6 waves (80 VGPRs, 240 B scratch) 12.0 / 108.1 ms, 5 waves 11.6 / 103.4,
-// 4 waves (128 VGPRs, 24 B) 12.5 / 101.2; the scratch shows up as HBM traffic (profiles/traffic.json c4, c5).
+// Instantiations: 64-thread workgroups (one wave, 8x8 tile: finer-grained scheduling, no intra-group imbalance)
+// for scenes of up to RT_PK_SMALL_SCENE objects -- the whole compiled scene in LDS up to RT_PK_SMALL_FULL objects
+// (108 VGPRs / 4 waves per SIMD, NO scratch), only the AABBs above that (COMPACT; PCF rays in pairs, 128 VGPRs) --
+// and 256-thread workgroups (16x16 tile, one AABB copy shared by four waves, 5 waves per SIMD = 96 VGPRs + 184 B/lane
+// of scratch) beyond.  Measured in DESIGN.md section 4 (C4: 4.0 -> 3.57 ms, C5: 12.7 -> 8.0 ms at 1080p against
+// four-wave workgroups with the whole scene in LDS).  Wave counts for the 256-thread shape, at full size
+// (C4 4K / C5 8K, before COMPACT): 6 waves (80 VGPRs, 240 B scratch) 12.0 / 108.1 ms, 5 waves 11.6 / 103.4,
+// 4 waves (128 VGPRs, 24 B) 12.5 / 101.2; the scratch shows up as HBM traffic.
 #ifndef RT_PK_WAVES_SMALL
 #define RT_PK_WAVES_SMALL 4
 #endif
@@ -687,7 +689,10 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #define RT_PK_WAVES_LARGE 5
 #endif
 #ifndef RT_PK_SMALL_SCENE
-#define RT_PK_SMALL_SCENE 32    // objects: at or below, use the one-wave workgroup
+#define RT_PK_SMALL_SCENE 256   // objects: at or below, one-wave workgroups (16 waves x (32 B/object + parking) fit a CU's LDS)
+#endif
+#ifndef RT_PK_SMALL_FULL
+#define RT_PK_SMALL_FULL 32     // objects: one-wave workgroups stage the whole scene up to here, only the AABBs above
 #endif
 #ifndef RT_PK_COMPACT_SCENE
 #define RT_PK_COMPACT_SCENE 144  // objects: above (5 workgroups x (160 B/object + parking) no longer fit a CU), stage only the AABBs in LDS
@@ -730,7 +735,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     const long long t0 = clock64();
 
     unsigned rays = 0;
-    render_packet<COUNT, BT>(f, dsc, sc, gColor, gPosition, gNormal, rays);
+    render_packet<COUNT, BT, (BT == 256 ? RT_PK_GROUP_LARGE : (COMPACT ? RT_PK_GROUP_SMALL_COMPACT : RT_PK_GROUP_SMALL))>(f, dsc, sc, gColor, gPosition, gNormal, rays);
 
     if (dsc.tileCost && (threadIdx.x & 63) == 0) {     // one add per wave: tile cost = sum of its waves' cycles / 64
         const unsigned c = (unsigned)(((unsigned long long)(clock64() - t0)) >> 6);
@@ -842,7 +847,11 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
         const bool small = bt == 64;
         dim3 grid(nTiles);
         const size_t ldsBytes = sceneBytes + 9 * bt * sizeof(float);                    // + the parking area
-        if (small) {
+        if (small && f.nObj > RT_PK_SMALL_FULL) {      // one-wave workgroups, AABBs only in LDS
+            const size_t compactBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) + 9 * bt * sizeof(float);
+            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+        } else if (small) {
             if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
             else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         } else if (f.nObj > RT_PK_COMPACT_SCENE) {

@@ -128,10 +128,10 @@ class StripPlan:
 
 def default_strip_rows(height, world, n_objects=None):
     """One workgroup tile per strip: 8 rows when the scene runs the one-wave 8x8-tile kernel
-    (<= 32 objects), 16 otherwise.  Short strips keep every rank's share of the benchmark scenes
+    (<= 256 objects), 16 otherwise.  Short strips keep every rank's share of the benchmark scenes
     within a few percent of equal and the padding of the equal-sized gather buffers small
     (1080p on 8 GPUs: 8-row strips pad 1080 -> 1088 rows, 16-row strips -> 1152)."""
-    if n_objects is not None and n_objects <= 32:
+    if n_objects is not None and n_objects <= 256:
         return 8
     return 16
 
