@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=1, help="1 = packet kernel (default), 0 = exhaustive loop")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="N>1: frames overlapping on the device, each on its own render stream (default 3; 1..4)")
+                    help="frames overlapping on the device, each on its own render stream (1..4; default 3 at N>1, "
+                         "1 at N=1 so that the per-kernel duration is the rocprofv3 one; N=1 with 2-3 measures 0.47 ms/frame)")
     ap.add_argument("--root-weight", type=int, default=0,
                     help="N>1: strips rank 0 owns per cycle (others own 1); 0 = autotune over 1,2,3,4,6 on untimed frames")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -115,7 +116,7 @@ def main():
     # tools/gpu_strip_scaling.py), so frame k+1 fills the CUs that frame k's short tiles have already left
     # (N = 8 share on one GPU: 0.25 ms/frame with F = 1, 0.13 with F = 2, 0.09 with F = 3).
     # The timed region still brackets K complete frames (render + gather + re-assembly, drained).
-    F = 1 if world == 1 else max(1, min(4, args.frames_in_flight or 3))
+    F = max(1, min(4, args.frames_in_flight or (1 if world == 1 else 3)))
     s_renders = [torch.cuda.Stream(device=dev) for _ in range(F)]
     s_render = s_renders[0]
     s_comm = torch.cuda.Stream(device=dev)
@@ -156,9 +157,9 @@ def main():
             k = self.k
             self.k += 1
             plan, p = self.plan, self.p
-            if world == 1:
-                c, q, n = self.views[0]
-                rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=s_render.cuda_stream)
+            if world == 1:          # F > 1 (opt-in): consecutive frames on alternating streams and surfaces
+                c, q, n = self.views[k % F]
+                rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=s_renders[k % F].cuda_stream)
                 return
             b, g2 = k % F, k & 1      # g2: rank 0's gather target (s_comm is in order, two are plenty)
             c, q, n = self.views[b]
@@ -235,9 +236,9 @@ def main():
         st.wait_event(ev0)
     for _ in range(args.steps):
         step()
+    for st in s_renders[1:]:
+        s_render.wait_stream(st)
     if world > 1:
-        for st in s_renders[1:]:
-            s_render.wait_stream(st)
         s_render.wait_stream(s_comm)      # the last frame's gather + re-assembly belongs to the timed region
     ev1.record(stream)
     fence()
@@ -306,7 +307,7 @@ def main():
                                        f"wire format ({plan.wire_bytes * (world - 1)} B into rank 0), {F} frames in flight "
                                        f"(render streams), gather k overlapped with the renders of the following frames")
                                       if world > 1 else "1 GPU",
-                       "root_weight": root_weight if world > 1 else None, "root_weight_autotune_ms_per_frame": tune,
+                       "frames_in_flight": F, "root_weight": root_weight if world > 1 else None, "root_weight_autotune_ms_per_frame": tune,
                        "rays_per_frame": frame_rays, "rays_per_pixel": round(frame_rays / n_px, 3)},
             "mpx_per_s": round(n_px * args.steps / elapsed / 1e6, 1), "rehearsal": bool(args.rehearse_on_one_gpu),
             "assembled_frame_equals_single_gpu_render": assembled_ok,
