@@ -50,6 +50,7 @@ struct rt_context {
     int fbCur = -1;                            // order buffer new launches read (-1 = raster order)
     int fbNext = 0;                            // order buffer the pending sort is writing
     bool sortPending = false;                  // a sort has been enqueued on the context's own stream, not yet adopted
+    unsigned sortAge = 0;                      // fbAge at which it was enqueued
     size_t capTiles = 0;
     int fbTiles = 0, fbTilesX = 0, fbBt = 0;   // geometry the current order was measured on (0 = none)
     unsigned fbAge = 0;                        // frames since that geometry was first seen
@@ -69,6 +70,7 @@ struct rt_context {
     bool frameAOValid = false;
     size_t capBloomPx = 0;
     bool feedback = true;
+    unsigned fbPeriod = 32;                    // re-sort period in frames (RT_FB_PERIOD overrides, for measurements)
     std::string err;
 };
 
@@ -240,9 +242,11 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             if (q == hipSuccess) {
                 c->fbCur = c->fbNext;
                 c->sortPending = false;
-            } else if (c->fbCur < 0) {
-                // no order at all yet (second frame of a geometry, host running ahead of the device): take the
-                // first order as soon as the device has it -- this stream waits for the sort, nothing else does
+            } else if (c->fbCur < 0 || c->fbAge - c->sortAge >= 1u + (unsigned)c->nFbStreams) {
+                // The host is running ahead of the device.  No order at all yet (second frame of a geometry), or
+                // the sort was issued more than one launch per render stream ago: it sits behind a frame that is no
+                // longer in flight when this launch reaches the device, so it is (all but) done -- take it through a
+                // stream wait instead of leaving a free-running host on a stale order for the rest of its run.
                 HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
                 c->fbCur = c->fbNext;
                 c->sortPending = false;
@@ -269,9 +273,11 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
     }
     if (sortAfter) {
         HIP_TRY(c, hipEventRecord(mine->last, s));
-        // Tile costs drift slowly from frame to frame: re-sort on the first two frames of a geometry,
-        // then every 8th (costs keep accumulating in between, which only smooths the estimate).
-        if ((c->fbAge < 2 || (c->fbAge & 7u) == 0) && !c->sortPending) {
+        // Re-sort on the first two frames of a geometry, then every fbPeriod-th.  Costs accumulate in between, so
+        // the order follows each tile's AVERAGE cost over the period: with a free-running frameCount (which rotates
+        // the bounce sample all pixels share) the last frame alone is a poor predictor of the next (C2, measured:
+        // 0.63 ms/frame ordering by the last frame every 8th, 0.56 by the 8-frame average, 0.54 by the 32-frame one).
+        if ((c->fbAge < 2 || (c->fbAge % c->fbPeriod) == 0) && !c->sortPending) {
             const int next = c->fbCur == 0 ? 1 : 0;
             // the buffer about to be rewritten was last read before the previous adoption: every stream's last
             // launch (this one included) is after those reads, and gives the sort this frame's costs
@@ -281,6 +287,7 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             HIP_TRY(c, hipEventRecord(c->evSort, c->stream));
             c->fbNext = next;
             c->sortPending = true;
+            c->sortAge = c->fbAge;
         }
         c->fbAge++;
         c->fbTiles = nTiles;
@@ -303,6 +310,10 @@ int rt_create(rt_context **out, int deviceId) {
     rt_context *c = new (std::nothrow) rt_context();
     if (!c) return RT_ERR_HIP;
     c->device = deviceId;
+    if (const char *e = getenv("RT_FB_PERIOD")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 1024) c->fbPeriod = (unsigned)v;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
         hipEventCreateWithFlags(&c->evScene, hipEventDisableTiming) != hipSuccess ||

@@ -739,7 +739,13 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
 
     if (dsc.tileCost && (threadIdx.x & 63) == 0) {     // one add per wave: tile cost = sum of its waves' cycles / 64
         const unsigned c = (unsigned)(((unsigned long long)(clock64() - t0)) >> 6);
-        if (BT == 64) dsc.tileCost[tile] = c;
+#ifndef RT_FB_ACCUM
+#define RT_FB_ACCUM 1
+#endif
+        // costs accumulate between two sorts (a one-wave tile has a single writer per frame, so a plain add does):
+        // the order then follows the tiles' average cost over the last period, which is what predicts the next
+        // frames when frameCount rotates the shared bounce sample from frame to frame
+        if (BT == 64) dsc.tileCost[tile] = RT_FB_ACCUM ? dsc.tileCost[tile] + c : c;
         else atomicAdd(&dsc.tileCost[tile], c);
     }
 
