@@ -685,6 +685,9 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #ifndef RT_PK_WAVES_SMALL
 #define RT_PK_WAVES_SMALL 4
 #endif
+#ifndef RT_PK_WAVES_SMALL_COMPACT
+#define RT_PK_WAVES_SMALL_COMPACT 4
+#endif
 #ifndef RT_PK_WAVES_LARGE
 #define RT_PK_WAVES_LARGE 5
 #endif
@@ -698,7 +701,7 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #define RT_PK_COMPACT_SCENE 144  // objects: above (5 workgroups x (160 B/object + parking) no longer fit a CU), stage only the AABBs in LDS
 #endif
 template <bool COUNT, int BT, bool COMPACT>
-__global__ __launch_bounds__(BT, (BT == 64 ? RT_PK_WAVES_SMALL : RT_PK_WAVES_LARGE))
+__global__ __launch_bounds__(BT, (BT == 64 ? (COMPACT ? RT_PK_WAVES_SMALL_COMPACT : RT_PK_WAVES_SMALL) : RT_PK_WAVES_LARGE))
 void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
                              float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
                              unsigned long long *rayCounter) {
