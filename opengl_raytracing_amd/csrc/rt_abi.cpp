@@ -362,7 +362,7 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     int rc;
     if ((rc = ensure(c, &c->dObjects, &c->capObjects, (size_t)nObj * RT_OBJECT_STRIDE))) return rc;
     if ((rc = ensure(c, &c->dLights, &c->capLights, (size_t)nLt * RT_LIGHT_STRIDE))) return rc;
-    if ((rc = ensure(c, &c->dCompiled, &c->capCompiledF4, rt_compiled_f4(nObj, nLt)))) return rc;
+    if ((rc = ensure(c, &c->dCompiled, &c->capCompiledF4, rt_compiled_total_f4(nObj, nLt)))) return rc;
     if (c->foreignPending) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evForeign, 0));
         c->foreignPending = false;

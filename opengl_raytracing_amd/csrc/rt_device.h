@@ -37,6 +37,11 @@ struct RtDeviceScene {
     unsigned *tileCost;
 };
 
+#define RT_PCF_TAB_N 16      // PCF samples tabulated per directional light (UI range of pcfSamples is 1..16)
+// float4 count of the whole compiled buffer: the staged part (rt_compiled_f4) + per light RT_PCF_TAB_N x 2 float4
+// of precomputed PCF rays (direction, dot(d,d)) (1/direction, -), meaningful for directional lights only
+static inline size_t rt_compiled_f4(int nObj, int nLt);
+static inline size_t rt_compiled_total_f4(int nObj, int nLt) { return rt_compiled_f4(nObj, nLt) + (size_t)nLt * RT_PCF_TAB_N * 2; }
 static inline size_t rt_compiled_f4(int nObj, int nLt) {
     return (size_t)nObj * (RT_HOT_F4 + RT_MAT_F4) + (size_t)nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
 }

@@ -125,6 +125,7 @@ struct SceneLds {
     // from the global copy.  hotStride = float4 stride of `hot`, matF4Base = material section in `global`.
     bool compact = false;
     int hotStride = RT_HOT_F4, matF4Base = 0;
+    int pcfTabF4 = -1;          // float4 index in `global` of the directional lights' PCF ray tables, -1 = not usable (noise bound)
 };
 
 // haltonSequence (raytracingCs.glsl:278-288); used by the scene compiler and as the
@@ -536,6 +537,28 @@ __global__ void rt_compile_scene_kernel(const uint8_t *objects, int nObj, const 
         h2[i] = halton_eval(i, 2);
         h3[i] = halton_eval(i, 3);
     }
+    // pcfShadow's jittered rays toward a DIRECTIONAL light (:352-375) do not depend on the shading point: with no
+    // noise texture bound (noise.rg = 0) sample s of every pixel, bounce and frame is the same ray.  Tabulate
+    // direction, dot(d,d) and 1/direction per light and sample with the expressions the per-lane path uses.
+    float4 *tab = (float4 *)(h3 + RT_HALTON_N);
+    for (int k = threadIdx.x; k < nLt * RT_PCF_TAB_N; k += blockDim.x) {
+        const int li = k / RT_PCF_TAB_N, sidx = k % RT_PCF_TAB_N;
+        const float *l = (const float *)(lights + (size_t)li * RT_LIGHT_STRIDE);
+        const int type = ((const int *)l)[0];
+        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        if (type == 1) {
+            const v3 lightDir = normalize(-V3(l[8], l[9], l[10]));
+            const float filterSize = l[18] * 0.005f;
+            const v3 tangent = normalize(cross(lightDir, V3(0.0f, 1.0f, 0.0f)));
+            const v3 bitangent = cross(lightDir, tangent);
+            const float rx = fract(halton_eval(sidx, 2) + 0.0f), ry = fract(halton_eval(sidx, 3) + 0.0f);
+            const v3 jd = (lightDir + (tangent * rx) * filterSize) + (bitangent * ry) * filterSize;
+            t0 = make_float4(jd.x, jd.y, jd.z, dot(jd, jd));
+            t1 = make_float4(1.0f / jd.x, 1.0f / jd.y, 1.0f / jd.z, 0.0f);
+        }
+        tab[2 * k] = t0;
+        tab[2 * k + 1] = t1;
+    }
 }
 
 // =========================================================================================
@@ -728,6 +751,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     sc.lgtF4Base = f.nObj * (RT_HOT_F4 + RT_MAT_F4);
     sc.haltonFloatBase = (sc.lgtF4Base + f.nLt * RT_LGT_F4) * 4;
     sc.park = (float *)(lds + nF4 + 1);      // after the staged scene and the 16-byte counter slot
+    sc.pcfTabF4 = dsc.noise ? -1 : nAll;     // the tables follow the staged sections in the global copy
 
     // tile of this workgroup: longest-first order from the previous frame's measured costs, if any
     constexpr int TILE_ = (BT == 256) ? 16 : 8;
