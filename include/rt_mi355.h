@@ -170,6 +170,11 @@ int rt_last_kernel_ms(rt_context *ctx, float *ms);
 /* Exact number of intersectObjects calls ("rays") for this frame,
  * counted by an instrumented build of the same kernel.  Synchronises. */
 int rt_count_rays(rt_context *ctx, const rt_params *p, uint64_t *rays);
+/* Rays the PRODUCTION kernel actually traverses for this frame: the same instrumented build, but keeping the
+ * skips the timed kernel applies to rays whose result provably cannot reach a pixel (shadow / PCSS-blocker rays of
+ * lanes whose light term is +-0 or NaN for every finite shadow value, blocker rays after the first blocker; DESIGN.md
+ * section 4 items 6-8).  <= rt_count_rays; equal for variant 0.  Synchronises. */
+int rt_count_rays_traced(rt_context *ctx, const rt_params *p, uint64_t *rays);
 
 /* Kernel variant: 1 (default) = wavefront-packet kernel (packet culling, scalar-fed traversal),
  * 0 = exhaustive per-lane loop over all objects.  Both produce bit-identical surfaces; the switch
@@ -186,6 +191,11 @@ int rt_debug_stats(rt_context *ctx, uint64_t out[4]);
  * last feedback-scheduled rt_render / rt_render_to launch, in raster tile order; synchronises.  Writes up
  * to cap entries, *nTiles / *tilesX describe the tile grid.  Measurement hook, no reference counterpart. */
 int rt_debug_tile_costs(rt_context *ctx, unsigned *out, int cap, int *nTiles, int *tilesX);
+
+/* The GL driver's own sin / cos / tan / exp as the path evaluates them (csrc/rt_mesa_math.h: tan(radians(fov)/2) of
+ * raytracingCs.glsl:209, cos/sin of :296-298, sin of random() :274, exp of :334), host side: out[4i..4i+3] =
+ * sin, cos, tan, exp of in[i].  Test hook (no GPU needed), no reference counterpart. */
+int rt_debug_mesa_math(const float *in, float *out, int n);
 
 const char *rt_last_error(rt_context *ctx);
 

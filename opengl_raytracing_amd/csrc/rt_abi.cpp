@@ -10,12 +10,12 @@
 #include <string>
 
 #include "rt_device.h"
+#include "rt_mesa_math.h"
 
 struct rt_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t evStart = nullptr, evStop = nullptr, evScene = nullptr, evForeign = nullptr;
-    bool foreignPending = false;
+    hipEvent_t evStart = nullptr, evStop = nullptr, evScene = nullptr;
     bool timed = false;
     // raw SSBO bytes + compiled scene
     uint8_t *dObjects = nullptr, *dLights = nullptr;
@@ -54,10 +54,15 @@ struct rt_context {
     size_t capTiles = 0;
     int fbTiles = 0, fbTilesX = 0, fbBt = 0;   // geometry the current order was measured on (0 = none)
     unsigned fbAge = 0;                        // frames since that geometry was first seen
-    struct FbStream { hipStream_t s; hipEvent_t last; };   // last feedback launch issued on each stream seen
-    FbStream fbStreams[4] = {};
+    // Every stream a render has been issued on (the context's own and the callers'): `last` = its most recent
+    // launch (recorded on EVERY launch, feedback or not: rt_set_scene orders the scene rewrite behind all of
+    // them), `seenGen` = the tile-order adoption it has already ordered itself behind.
+    struct FbStream { hipStream_t s; hipEvent_t last; unsigned seenGen; };
+    static constexpr int kMaxStreams = 8;
+    FbStream fbStreams[kMaxStreams] = {};
     int nFbStreams = 0;
-    hipEvent_t evSort = nullptr;               // completion of the last rt_lpt_sort (adopted once hipEventQuery says done)
+    hipEvent_t evSort[2] = {nullptr, nullptr}; // completion of the rt_lpt_sort that wrote dTileOrder[k]
+    unsigned adoptGen = 0;                     // bumped whenever fbCur changes to a freshly sorted buffer
     void *dBloom[2] = {nullptr, nullptr};      // rgba16f ping-pong targets of rt_bloom
     float *dSsaoDepth = nullptr;               // gPosition.z plane of rt_ssao
     size_t capSsaoPx = 0;
@@ -125,9 +130,9 @@ void hemi_local(float rx, float ry, float out[4]) {
     float phi = 2.0f * PI_F * rx;
     float cosTheta = sqrtf(ry);
     float sinTheta = sqrtf(1.0f - ry);
-    out[0] = sinTheta * cosf(phi);
+    out[0] = sinTheta * rtm::cos_(phi);      // the reference GL's own cos / sin (rt_mesa_math.h), not libm's
     out[1] = cosTheta;
-    out[2] = sinTheta * sinf(phi);
+    out[2] = sinTheta * rtm::sin_(phi);
     out[3] = 0.0f;
 }
 
@@ -162,7 +167,9 @@ void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
     f->skySize = c->skySize;
     // generateCameraRay (:208-211): aspect, tan(radians(fov)*0.5); radians(x) = x*fl(pi/180)
     float aspect = (float)p->width / (float)p->height;
-    float tanFov = tanf((p->fovDeg * 0.017453292519943295f) * 0.5f);
+    // Mesa's tan = sin/cos by its own polynomials (rt_mesa_math.h); libm's tanf is 1 ulp off at fov 45, which
+    // perturbs every camera ray and showed up as silhouette flips against the reference's pixels
+    float tanFov = rtm::tan_((p->fovDeg * 0.017453292519943295f) * 0.5f);
     f->sx = aspect * tanFov * p->focalLength;
     f->sy = tanFov * p->focalLength;
     // hammersley(depth*64 + frameCount, 64) (:557, :311-313): same sample for every pixel
@@ -176,8 +183,31 @@ void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
 hipError_t fb_sync_all(rt_context *c) {
     hipError_t e = hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->nFbStreams && e == hipSuccess; i++) e = hipEventSynchronize(c->fbStreams[i].last);
-    if (e == hipSuccess && c->evSort) e = hipEventSynchronize(c->evSort);
+    for (int k = 0; k < 2 && e == hipSuccess; k++)
+        if (c->evSort[k]) e = hipEventSynchronize(c->evSort[k]);
     return e;
+}
+
+// The record of stream s (created on first use).  More streams than slots: drain and start over (not a hot path).
+int stream_record(rt_context *c, hipStream_t s, rt_context::FbStream **out) {
+    for (int i = 0; i < c->nFbStreams; i++)
+        if (c->fbStreams[i].s == s) { *out = &c->fbStreams[i]; return RT_OK; }
+    if (c->nFbStreams == rt_context::kMaxStreams) {
+        hipError_t e = fb_sync_all(c);
+        if (e != hipSuccess) return fail(c, RT_ERR_HIP, "fb_sync_all", e);
+        c->nFbStreams = 0;
+    }
+    rt_context::FbStream *m = &c->fbStreams[c->nFbStreams++];
+    m->s = s;
+    m->seenGen = 0;                // adoptGen starts at 1 with the first adoption: a new stream always orders itself
+    if (!m->last) {
+        hipError_t e = hipEventCreateWithFlags(&m->last, hipEventDisableTiming);
+        if (e != hipSuccess) { c->nFbStreams--; return fail(c, RT_ERR_HIP, "hipEventCreateWithFlags", e); }
+    }
+    hipError_t e = hipEventRecord(m->last, s);
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, "hipEventRecord", e);
+    *out = m;
+    return RT_OK;
 }
 
 hipError_t fb_wait_others(rt_context *c, const rt_context::FbStream *mine, hipStream_t s) {
@@ -190,7 +220,7 @@ hipError_t fb_wait_others(rt_context *c, const rt_context::FbStream *mine, hipSt
 }
 
 int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint2 *dNormal,
-           unsigned long long *counter, hipStream_t s, bool timed) {
+           unsigned long long *counter, hipStream_t s, bool timed, int countMode = 1) {
     RtFrame f;
     build_frame(c, p, &f);
     RtDeviceScene sc;
@@ -205,6 +235,10 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
     bool sortAfter = false;
     int bt = 0, tile = 0, tilesX = 0, nTiles = 0;
     rt_context::FbStream *mine = nullptr;
+    {
+        const int rc = stream_record(c, s, &mine);
+        if (rc) return rc;
+    }
     if (c->variant == 1 && c->feedback && !counter && p->regionW > 0 && p->regionH > 0) {
         rt_packet_geometry(c->nObj, p->regionW, p->regionH, &bt, &tile, &tilesX, &nTiles);
         if ((size_t)nTiles > c->capTiles) {
@@ -216,63 +250,62 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             c->capTiles = 0;
             c->fbTiles = 0;
             c->fbCur = -1;
+            c->sortPending = false;
             HIP_TRY(c, hipMalloc((void **)&c->dTileCost, (size_t)nTiles * sizeof(unsigned)));
             HIP_TRY(c, hipMalloc((void **)&c->dTileSnap, (size_t)nTiles * sizeof(unsigned)));
             HIP_TRY(c, hipMalloc((void **)&c->dTileOrder[0], (size_t)nTiles * sizeof(unsigned)));
             HIP_TRY(c, hipMalloc((void **)&c->dTileOrder[1], (size_t)nTiles * sizeof(unsigned)));
             c->capTiles = (size_t)nTiles;
         }
-        for (int i = 0; i < c->nFbStreams; i++)
-            if (c->fbStreams[i].s == s) mine = &c->fbStreams[i];
-        if (!mine) {
-            if (c->nFbStreams == 4) {          // more streams than slots: drain and start over (not a hot path)
-                HIP_TRY(c, fb_sync_all(c));
-                c->nFbStreams = 0;
-            }
-            mine = &c->fbStreams[c->nFbStreams++];
-            mine->s = s;
-            if (!mine->last) HIP_TRY(c, hipEventCreateWithFlags(&mine->last, hipEventDisableTiming));
-            HIP_TRY(c, hipEventRecord(mine->last, s));
-        }
-        // The sort runs on the context's own stream, beside the frames; its order is adopted by the first launch
-        // issued after it has completed, so no render stream ever waits for it.
-        if (c->sortPending) {
-            const hipError_t q = hipEventQuery(c->evSort);
-            (void)hipGetLastError();           // hipErrorNotReady is an answer, not an error to find later
-            if (q == hipSuccess) {
-                c->fbCur = c->fbNext;
-                c->sortPending = false;
-            } else if (c->fbCur < 0 || c->fbAge - c->sortAge >= 1u + (unsigned)c->nFbStreams) {
-                // The host is running ahead of the device.  No order at all yet (second frame of a geometry), or
-                // the sort was issued more than one launch per render stream ago: it sits behind a frame that is no
-                // longer in flight when this launch reaches the device, so it is (all but) done -- take it through a
-                // stream wait instead of leaving a free-running host on a stale order for the rest of its run.
-                HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
-                c->fbCur = c->fbNext;
-                c->sortPending = false;
-            }
-        }
         const bool same = c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt;
-        if (!same) {                           // new geometry: nobody may still be using the old costs / order
+        if (!same) {
+            // New geometry: nobody may still be using the old costs / orders, and a sort of the old geometry must
+            // never be adopted.  Both order buffers restart as the identity permutation (a launch that reads one
+            // before its first sort -- it cannot, fbCur is -1 -- would still visit every tile exactly once).
             HIP_TRY(c, fb_wait_others(c, mine, s));
-            if (c->evSort) HIP_TRY(c, hipStreamWaitEvent(s, c->evSort, 0));
+            for (int k = 0; k < 2; k++)
+                if (c->evSort[k]) HIP_TRY(c, hipStreamWaitEvent(s, c->evSort[k], 0));
             HIP_TRY(c, hipMemsetAsync(c->dTileCost, 0, (size_t)nTiles * sizeof(unsigned), s));
+            HIP_TRY(c, rt_launch_iota(c->dTileOrder[0], nTiles, s));
+            HIP_TRY(c, rt_launch_iota(c->dTileOrder[1], nTiles, s));
+            HIP_TRY(c, hipEventRecord(mine->last, s));      // later sorts (context stream) order behind the re-initialisation
             c->fbCur = -1;
             c->sortPending = false;
             c->fbAge = 0;
+        } else if (c->sortPending) {
+            // The sort runs on the context's own stream, beside the frames; its order is adopted by the first launch
+            // issued after it has completed, so no render stream waits for a sort in steady state.
+            const hipError_t q = hipEventQuery(c->evSort[c->fbNext]);
+            (void)hipGetLastError();           // hipErrorNotReady is an answer, not an error to find later
+            // Not ready: the host is running ahead of the device.  No order at all yet (second frame of a geometry),
+            // or the sort was issued more than one launch per render stream ago (it sits behind a frame that is no
+            // longer in flight when this launch reaches the device, so it is all but done): adopt it anyway -- every
+            // stream orders itself behind the sort's event on its next launch (seenGen below).
+            if (q == hipSuccess || c->fbCur < 0 || c->fbAge - c->sortAge >= 1u + (unsigned)c->nFbStreams) {
+                c->fbCur = c->fbNext;
+                c->sortPending = false;
+                c->adoptGen++;
+            }
+        }
+        // EVERY stream's first launch after an adoption waits for the sort that wrote the adopted buffer (a no-op
+        // once it has completed).  Adoption state is context-global, streams are not ordered with each other: without
+        // this, a frame on stream B could read an order that only stream A had waited for.
+        if (c->fbCur >= 0 && mine->seenGen != c->adoptGen) {
+            HIP_TRY(c, hipStreamWaitEvent(s, c->evSort[c->fbCur], 0));
+            mine->seenGen = c->adoptGen;
         }
         sc.tileOrder = c->fbCur >= 0 ? c->dTileOrder[c->fbCur] : nullptr;
         sc.tileCost = c->dTileCost;
         sortAfter = true;
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->evStart, s));
-    HIP_TRY(c, rt_launch_render(f, sc, dColor, dPos, dNormal, counter, c->variant, s));
+    HIP_TRY(c, rt_launch_render(f, sc, dColor, dPos, dNormal, counter, c->variant, s, countMode));
     if (timed) {
         HIP_TRY(c, hipEventRecord(c->evStop, s));
         c->timed = true;
     }
+    HIP_TRY(c, hipEventRecord(mine->last, s));      // every launch, on every stream: rt_set_scene orders behind it
     if (sortAfter) {
-        HIP_TRY(c, hipEventRecord(mine->last, s));
         // Re-sort on the first two frames of a geometry, then every fbPeriod-th.  Costs accumulate in between, so
         // the order follows each tile's AVERAGE cost over the period: with a free-running frameCount (which rotates
         // the bounce sample all pixels share) the last frame alone is a poor predictor of the next (C2, measured:
@@ -283,8 +316,8 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             // launch (this one included) is after those reads, and gives the sort this frame's costs
             for (int i = 0; i < c->nFbStreams; i++) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->fbStreams[i].last, 0));
             HIP_TRY(c, rt_launch_lpt_sort(c->dTileCost, c->dTileSnap, c->dTileOrder[next], nTiles, c->stream));
-            if (!c->evSort) HIP_TRY(c, hipEventCreateWithFlags(&c->evSort, hipEventDisableTiming));
-            HIP_TRY(c, hipEventRecord(c->evSort, c->stream));
+            if (!c->evSort[next]) HIP_TRY(c, hipEventCreateWithFlags(&c->evSort[next], hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->evSort[next], c->stream));
             c->fbNext = next;
             c->sortPending = true;
             c->sortAge = c->fbAge;
@@ -317,7 +350,6 @@ int rt_create(rt_context **out, int deviceId) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
         hipEventCreateWithFlags(&c->evScene, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evForeign, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->dRayCounter, 4 * sizeof(unsigned long long)) != hipSuccess) {
         rt_destroy(c);
         return RT_ERR_HIP;
@@ -330,7 +362,7 @@ int rt_destroy(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < rt_context::kMaxStreams; i++)
         if (c->fbStreams[i].last) {
             (void)hipEventSynchronize(c->fbStreams[i].last);
             (void)hipEventDestroy(c->fbStreams[i].last);
@@ -342,8 +374,8 @@ int rt_destroy(rt_context *c) {
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->evScene) (void)hipEventDestroy(c->evScene);
-    if (c->evForeign) (void)hipEventDestroy(c->evForeign);
-    if (c->evSort) (void)hipEventDestroy(c->evSort);
+    for (int k = 0; k < 2; k++)
+        if (c->evSort[k]) (void)hipEventDestroy(c->evSort[k]);
     for (int k = 0; k < 2; k++) {
         if (c->evStage[k]) (void)hipEventDestroy(c->evStage[k]);
         if (c->hStage[k]) (void)hipHostFree(c->hStage[k]);
@@ -363,10 +395,11 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     if ((rc = ensure(c, &c->dObjects, &c->capObjects, (size_t)nObj * RT_OBJECT_STRIDE))) return rc;
     if ((rc = ensure(c, &c->dLights, &c->capLights, (size_t)nLt * RT_LIGHT_STRIDE))) return rc;
     if ((rc = ensure(c, &c->dCompiled, &c->capCompiledF4, rt_compiled_total_f4(nObj, nLt)))) return rc;
-    if (c->foreignPending) {
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evForeign, 0));
-        c->foreignPending = false;
-    }
+    // The scene buffers are about to be rewritten on the context's stream: order that behind the last launch of
+    // EVERY stream frames have been issued on (one event per stream; a single shared event would only cover the
+    // most recent one -- ADVICE r1).  The reference re-uploads its SSBOs every frame, so this is the common path.
+    for (int i = 0; i < c->nFbStreams; i++)
+        if (c->fbStreams[i].s != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->fbStreams[i].last, 0));
     const size_t objBytes = (size_t)nObj * RT_OBJECT_STRIDE, ltBytes = (size_t)nLt * RT_LIGHT_STRIDE;
     const int k = (int)(c->stageSeq++ & 1u);
     if (c->stageUsed[k]) HIP_TRY(c, hipEventSynchronize(c->evStage[k]));
@@ -455,12 +488,7 @@ int rt_render_to(rt_context *c, const rt_params *p, void *dColor, void *dPositio
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
     if (s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->evScene, 0));
-    rc = launch(c, p, (float4 *)dColor, (float4 *)dPosition, (uint2 *)dNormal, nullptr, s, true);
-    if (rc == RT_OK && s != c->stream) {   // the next rt_set_scene must not overwrite the scene under this launch
-        HIP_TRY(c, hipEventRecord(c->evForeign, s));
-        c->foreignPending = true;
-    }
-    return rc;
+    return launch(c, p, (float4 *)dColor, (float4 *)dPosition, (uint2 *)dNormal, nullptr, s, true);
 }
 
 int rt_sync(rt_context *c) {
@@ -500,7 +528,10 @@ int rt_last_kernel_ms(rt_context *c, float *ms) {
     return RT_OK;
 }
 
-int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) {
+static int count_rays_impl(rt_context *c, const rt_params *p, uint64_t *rays, int countMode);
+int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) { return count_rays_impl(c, p, rays, 1); }
+int rt_count_rays_traced(rt_context *c, const rt_params *p, uint64_t *rays) { return count_rays_impl(c, p, rays, 2); }
+static int count_rays_impl(rt_context *c, const rt_params *p, uint64_t *rays, int countMode) {
     if (!c || !rays) return RT_ERR_INVALID_ARG;
     int rc = validate_params(c, p);
     if (rc) return rc;
@@ -515,7 +546,7 @@ int rt_count_rays(rt_context *c, const rt_params *p, uint64_t *rays) {
     if (e1 == hipSuccess && e2 == hipSuccess) {
         rc = RT_OK;
         if (hipMemsetAsync(c->dRayCounter, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = RT_ERR_HIP;
-        if (!rc) rc = launch(c, p, col, pos, nrm, c->dRayCounter, c->stream, false);
+        if (!rc) rc = launch(c, p, col, pos, nrm, c->dRayCounter, c->stream, false, countMode);
         unsigned long long v[4] = {0, 0, 0, 0};
         if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess ||
                     hipMemcpy(v, c->dRayCounter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess))
@@ -593,6 +624,17 @@ int rt_bloom(rt_context *c, const void *dScene, void *dOut, int width, int heigh
 }
 
 const char *rt_last_error(rt_context *c) { return c ? c->err.c_str() : "NULL context"; }
+
+int rt_debug_mesa_math(const float *in, float *out, int n) {
+    if (!in || !out || n < 0) return RT_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++) {
+        out[4 * i] = rtm::sin_(in[i]);
+        out[4 * i + 1] = rtm::cos_(in[i]);
+        out[4 * i + 2] = rtm::tan_(in[i]);
+        out[4 * i + 3] = rtm::exp_(in[i]);
+    }
+    return RT_OK;
+}
 
 int rt_equirect_to_cubemap(rt_context *c, const float *hEquirectRGB, int width, int height, int size, void *dFacesOut,
                            int install) {

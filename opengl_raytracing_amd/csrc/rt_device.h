@@ -50,11 +50,12 @@ static inline size_t rt_compiled_f4(int nObj, int nLt) {
 hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint8_t *dLights, int nLt,
                                    float4 *dCompiled, hipStream_t s);
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
-                            uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s);
+                            uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s, int countMode = 1);
 // Tile geometry of the packet kernel for a given scene size / window (so the ABI layer can size the
 // feedback buffers): workgroup threads, tile edge, tiles per row, total tiles.
 void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles);
 hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s);
+hipError_t rt_launch_iota(unsigned *dOrder, int n, hipStream_t s);      // dOrder[i] = i (identity tile order)
 hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
                                  float blend, float jx, float jy, hipStream_t s);
 hipError_t rt_launch_ssao(const void *position, const void *normal, void *depthPlane, void *out, int W, int H, const float *noise,

@@ -20,6 +20,7 @@
 // -ffp-contract=off; IEEE divide/sqrt) so results are comparable bit-for-bit with the CPU
 // restatement in oracle/ wherever no transcendental is involved.
 #include "rt_device.h"
+#include "rt_mesa_math.h"
 
 #include <hip/hip_fp16.h>
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 // mix(): Mesa lowers the built-in context-dependently; the two shapes the shader uses were
-// probed bitwise on llvmpipe (tests/test_reference_probes.py):
+// probed bitwise on llvmpipe (tests/test_oracle_units.py, fixture tests/golden/probes.npz):
 //   all-variable operands (:562)  -> a + t*(b-a);   constant first operand (:240) -> a*(1-t) + b*t
 __device__ __forceinline__ v3 mix_fast(v3 a, v3 b, float t) { return a + (b - a) * t; }
 __device__ __forceinline__ v3 mix_strict(v3 a, v3 b, float t) { return a * (1.0f - t) + b * t; }
@@ -69,40 +70,10 @@ __device__ __forceinline__ float pow5(float x) {
     return x < 0.0f ? __int_as_float(0x7fc00000) : r;
 }
 
-// Deterministic sin / exp in IEEE double +,* only (same source as oracle/rt_oracle.c, so the
-// two agree bit for bit; correctly rounded to fp32 on every sample tested).  Used once per
-// Russian-roulette decision (random(), :274) and once per SSS hit (:334) -- off the hot loop;
-// MI355X's full-rate fp64 makes this cheaper than an fp32 Payne-Hanek reduction.
-__device__ __forceinline__ float det_sinf(float xf) {
-    double x = (double)xf;
-    if (!(fabs(x) < 1.0e9)) return xf - xf;
-    double kd = rint(x * 0.63661977236758134308);
-    long long k = (long long)kd;
-    double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
-    double r2 = r * r;
-    double s = r + r * (r2 * (-1.66666666666666324348e-01 + r2 * (8.33333333332248946124e-03 + r2 * (-1.98412698298579493134e-04 +
-               r2 * (2.75573137070700676789e-06 + r2 * (-2.50507602534068634195e-08 + r2 * 1.58969099521155010221e-10))))));
-    double c = 1.0 + r2 * (-0.5 + r2 * (4.16666666666666019037e-02 + r2 * (-1.38888888888741095749e-03 +
-               r2 * (2.48015872894767294178e-05 + r2 * (-2.75573143513906633035e-07 + r2 * 2.08757232129817482790e-09)))));
-    double v = (k & 1) ? c : s;
-    if (k & 2) v = -v;
-    return (float)v;
-}
-
-__device__ __forceinline__ float det_expf(float xf) {
-    double x = (double)xf;
-    if (x != x) return xf;
-    if (x > 89.0) return __int_as_float(0x7f800000);
-    if (x < -104.0) return 0.0f;
-    double kd = rint(x * 1.44269504088896338700e+00);
-    double r = (x - kd * 6.93147180369123816490e-01) - kd * 1.90821492927058770002e-10;
-    double p = 1.0 + r * (1.0 + r * (0.5 + r * (1.66666666666666666667e-01 + r * (4.16666666666666666667e-02 +
-               r * (8.33333333333333333333e-03 + r * (1.38888888888888888889e-03 + r * (1.98412698412698412698e-04 +
-               r * (2.48015873015873015873e-05 + r * (2.75573192239858906526e-06 + r * 2.75573192239858906526e-07)))))))));
-    long long k = (long long)kd;
-    double sc = __longlong_as_double((long long)((unsigned long long)(k + 1023) << 52));
-    return (float)(p * sc);
-}
+// sin of random() (:274, one per Russian-roulette decision) and exp of the SSS term (:334): the reference GL's
+// own polynomials (rt_mesa_math.h), so roulette decisions are the reference's, bit for bit.  fp32 + FMA only.
+__device__ __forceinline__ float det_sinf(float x) { return rtm::sin_(x); }
+__device__ __forceinline__ float det_expf(float x) { return rtm::exp_(x); }
 
 constexpr float PI_F = 3.14159265359f;  // raytracingCs.glsl:6
 
@@ -185,7 +156,7 @@ __device__ __forceinline__ bool shape_test(const Ray &r, float a, const float4 *
 }
 
 // intersectObjects (:155-196), closest hit.  Returns the object index or -1; t = minT.
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ int trace_closest(const SceneLds &sc, int nObj, const Ray &r, float maxDist,
                                               float &tOut, unsigned &rays) {
     if (COUNT) rays++;
@@ -212,7 +183,7 @@ __device__ __forceinline__ int trace_closest(const SceneLds &sc, int nObj, const
 // 0 < t < limit, limit = min(maxRayDistance, lightDistance) for point/area lights and
 // maxRayDistance for directional ones (exactly the reference's closest-hit test, A.1#14).
 // Lanes that found an occluder idle; the loop ends when the whole wave is done.
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ bool trace_any(const SceneLds &sc, int nObj, const Ray &r, float maxDist,
                                            float limit, unsigned &rays) {
     if (COUNT) rays++;
@@ -359,7 +330,7 @@ __device__ __forceinline__ float halton_lookup(const float *table, int i, int ba
 }
 
 // pcfShadow (:342-397)
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ float pcf_shadow(const SceneLds &sc, const RtFrame &f, v3 origin, int ltype,
                                              int pcfSamples, float filterSize, v3 lightDir, float limit,
                                              float jitterR, unsigned &rays) {
@@ -379,7 +350,7 @@ __device__ __forceinline__ float pcf_shadow(const SceneLds &sc, const RtFrame &f
 }
 
 // pcssShadow (:400-440): 16 blocker-search rays; any blocker -> plain PCF (penumbra size is dead)
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ float pcss_shadow(const SceneLds &sc, const RtFrame &f, v3 origin, int ltype,
                                               int pcfSamples, float filterSize, float searchSize, v3 lightDir,
                                               float limit, float jitterR, unsigned &rays) {
@@ -395,7 +366,7 @@ __device__ __forceinline__ float pcss_shadow(const SceneLds &sc, const RtFrame &
 }
 
 // computeSubsurfaceScattering (:316-339)
-template <bool COUNT>
+template <int COUNT>
 __device__ v3 compute_sss(const SceneLds &sc, const RtFrame &f, v3 P, v3 N, const Mat &m, unsigned &rays) {
     v3 sss = V3(0.0f, 0.0f, 0.0f);
     for (int i = 0; i < 4; i++) {
@@ -413,7 +384,7 @@ __device__ v3 compute_sss(const SceneLds &sc, const RtFrame &f, v3 P, v3 N, cons
 }
 
 // computeLighting (:457-507)
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ v3 compute_lighting(const SceneLds &sc, const RtFrame &f, v3 P, v3 N, const Mat &m,
                                                 v3 V, float jitterR, unsigned &rays) {
     v3 Lo = V3(0.0f, 0.0f, 0.0f);
@@ -572,7 +543,7 @@ __global__ void rt_compile_scene_kernel(const uint8_t *objects, int nObj, const 
 #else
 #define RT_V0_BOUNDS __launch_bounds__(BLOCK_THREADS)
 #endif
-template <bool COUNT>
+template <int COUNT>
 __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceScene dsc,
                                                                   float4 *__restrict__ gColor,
                                                                   float4 *__restrict__ gPosition,
@@ -723,7 +694,7 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #ifndef RT_PK_COMPACT_SCENE
 #define RT_PK_COMPACT_SCENE 144  // objects: above (5 workgroups x (160 B/object + parking) no longer fit a CU), stage only the AABBs in LDS
 #endif
-template <bool COUNT, int BT, bool COMPACT>
+template <int COUNT, int BT, bool COMPACT>
 __global__ __launch_bounds__(BT, (BT == 64 ? (COMPACT ? RT_PK_WAVES_SMALL_COMPACT : RT_PK_WAVES_SMALL) : RT_PK_WAVES_LARGE))
 void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
                              float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
@@ -757,6 +728,9 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     constexpr int TILE_ = (BT == 256) ? 16 : 8;
     const int tilesX = (f.p.regionW + TILE_ - 1) / TILE_;
     const unsigned tile = dsc.tileOrder ? dsc.tileOrder[blockIdx.x] : blockIdx.x;
+    // an order buffer is a permutation of [0, gridDim.x) by construction (identity-initialised, rewritten only by
+    // rt_lpt_sort_kernel); the guard keeps a corrupted entry from turning into out-of-bounds tileCost / surface writes
+    if (tile >= gridDim.x) return;
     sc.tileX = (int)(tile % (unsigned)tilesX);
     sc.tileY = (int)(tile / (unsigned)tilesX);
     const long long t0 = clock64();
@@ -870,8 +844,11 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
     return hipGetLastError();
 }
 
+// countMode (only with dRayCounter): 1 = instrumented build that traces every ray the REFERENCE traces (its count is the
+// unit count R of the metric), 2 = instrumented build that keeps the production kernel's provably-dead-ray skips
+// (its count is what the timed kernel actually traverses).
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
-                            uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s) {
+                            uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s, int countMode) {
     if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
     const size_t sceneBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
     if (variant == 1) {
@@ -882,25 +859,29 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
         const size_t ldsBytes = sceneBytes + 9 * bt * sizeof(float);                    // + the parking area
         if (small && f.nObj > RT_PK_SMALL_FULL) {      // one-wave workgroups, AABBs only in LDS
             const size_t compactBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) + 9 * bt * sizeof(float);
-            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         } else if (small) {
-            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         } else if (f.nObj > RT_PK_COMPACT_SCENE) {
             const size_t compactBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) + 9 * bt * sizeof(float);
-            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         } else {
-            if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<true, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<false, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         }
     } else {
         dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
         if (dRayCounter)
-            hipLaunchKernelGGL(rt_render_kernel<true>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            hipLaunchKernelGGL(rt_render_kernel<1>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
         else
-            hipLaunchKernelGGL(rt_render_kernel<false>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
+            hipLaunchKernelGGL(rt_render_kernel<0>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
     }
     return hipGetLastError();
 }
@@ -950,6 +931,17 @@ __global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict_
         order[pos] = (unsigned)i;
     }
     for (int i = threadIdx.x; i < nTiles; i += 1024) cost[i] = 0;
+}
+
+__global__ void rt_iota_kernel(unsigned *__restrict__ order, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = (unsigned)i;
+}
+
+hipError_t rt_launch_iota(unsigned *dOrder, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dOrder, n);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s) {

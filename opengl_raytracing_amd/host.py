@@ -31,10 +31,10 @@ _LIB = None
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
-    "rt_count_rays", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
+    "rt_count_rays", "rt_count_rays_traced", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
     "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_frame", "rt_frame_surfaces", "rt_strip_local_rows", "rt_deinterleave",
-    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack",
+    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack", "rt_debug_mesa_math",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library(build_if_missing=True):
     lib.rt_get_surfaces.argtypes = [vp, P(vp), P(vp), P(vp)]
     lib.rt_last_kernel_ms.argtypes = [vp, P(ctypes.c_float)]
     lib.rt_count_rays.argtypes = [vp, P(L.RtParams), P(ctypes.c_uint64)]
+    lib.rt_count_rays_traced.argtypes = [vp, P(L.RtParams), P(ctypes.c_uint64)]
     lib.rt_set_variant.argtypes = [vp, ci]
     lib.rt_debug_stats.argtypes = [vp, P(ctypes.c_uint64)]
     lib.rt_debug_tile_costs.argtypes = [vp, P(ctypes.c_uint32), ci, P(ci), P(ci)]
@@ -108,6 +109,7 @@ def load_library(build_if_missing=True):
     lib.rt_wire_bytes.restype = ctypes.c_size_t
     lib.rt_wire_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.rt_wire_unpack.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.rt_debug_mesa_math.argtypes = [vp, vp, ci]
     for name in EXPORTS:
         if name != "rt_last_error":
             getattr(lib, name).restype = ci
@@ -206,6 +208,16 @@ def taa_jitter(frame_count, width, height):
     if rc:
         raise RtError(rc, "rt_taa_jitter")
     return jx.value, jy.value
+
+
+def mesa_math(x):
+    """(sin, cos, tan, exp) of float32 x as the HIP path's host side evaluates them (csrc/rt_mesa_math.h)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((len(x), 4), dtype=np.float32)
+    rc = load_library().rt_debug_mesa_math(_ptr(x), _ptr(out), len(x))
+    if rc:
+        raise RtError(rc, "rt_debug_mesa_math")
+    return out
 
 
 def strip_local_rows(height, strip_rows, strip_count, strip_index):
@@ -317,6 +329,12 @@ class RayTracer:
     def count_rays(self, params):
         n = ctypes.c_uint64()
         self._check(self.lib.rt_count_rays(self.ctx, ctypes.byref(params), ctypes.byref(n)), "rt_count_rays")
+        return n.value
+
+    def count_rays_traced(self, params):
+        """Rays the production kernel traverses (keeps its dead-ray skips); <= count_rays."""
+        n = ctypes.c_uint64()
+        self._check(self.lib.rt_count_rays_traced(self.ctx, ctypes.byref(params), ctypes.byref(n)), "rt_count_rays_traced")
         return n.value
 
     def taa_resolve(self, d_current, d_history, d_normal, d_out, width, height, blend, jx, jy, stream=None):

@@ -143,9 +143,11 @@ def write_job(path, scene, params):
             f.write(np.ascontiguousarray(sky, dtype=np.float16).tobytes())
 
 
-def run_reference(scene, params, repeat=0, shipped_dispatch=False, threads=None, glsl=REFERENCE_GLSL):
-    """Run the reference's GLSL unmodified (full frame only: GL compute has no dispatch
-    offset).  -> (gColor, gPosition, gNormal-as-f32, info dict)."""
+def run_reference(scene, params, repeat=0, shipped_dispatch=False, threads=None, glsl=REFERENCE_GLSL, groups=None, crop=None):
+    """Run the reference's GLSL unmodified.  GL compute has no dispatch offset, so the default is the
+    full frame; `groups=(gx, gy)` dispatches only the bottom-left gx x gy workgroups of 32x32 pixels of
+    the full-size images (same invocations as in the full dispatch), `crop=(x0, y0, w, h)` returns only
+    that window.  -> (gColor, gPosition, gNormal-as-f32, info dict)."""
     if not harness_available():
         raise RuntimeError("gl_harness or the reference GLSL is not available here")
     w, h = params.width, params.height
@@ -155,6 +157,11 @@ def run_reference(scene, params, repeat=0, shipped_dispatch=False, threads=None,
         cmd = [HARNESS, "render", glsl, job, os.path.join(d, "out"), "--repeat", str(repeat)]
         if shipped_dispatch:
             cmd.append("--shipped-dispatch")
+        if groups:
+            cmd += ["--groups", str(groups[0]), str(groups[1])]
+        if crop:
+            cmd += ["--crop"] + [str(int(v)) for v in crop]
+            w, h = int(crop[2]), int(crop[3])
         env = dict(os.environ)
         if threads:
             env["LP_NUM_THREADS"] = str(threads)
@@ -290,3 +297,25 @@ def mesa_atan2_asin(y, x, z):
     a, s = np.zeros_like(y), np.zeros_like(y)
     lib.orc_mesa_atan2_asin(_ptr(y), _ptr(x), _ptr(z), len(y), _ptr(a), _ptr(s))
     return a, s
+
+
+def mesa_trig(x):
+    """(sin, cos, tan) of float32 x as oracle/rt_oracle.c's mesa_sinf / mesa_cosf / mesa_tanf evaluate them."""
+    lib = load()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orc_mesa_trig.argtypes = [vp, vp, ci]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((len(x), 3), dtype=np.float32)
+    lib.orc_mesa_trig(_ptr(x), _ptr(out), len(x))
+    return out
+
+
+def mesa_explog(x):
+    """(log2, exp2, pow(x,5), exp) of float32 x as the oracle's mesa_* restatements evaluate them."""
+    lib = load()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orc_mesa_explog.argtypes = [vp, vp, ci]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((len(x), 4), dtype=np.float32)
+    lib.orc_mesa_explog(_ptr(x), _ptr(out), len(x))
+    return out

@@ -17,6 +17,9 @@
  *
  * Modes
  *   gl_harness render <shader.glsl> <job.bin> <out_prefix> [--repeat N] [--shipped-dispatch]
+ *                     [--groups GX GY] [--crop X0 Y0 W H]
+ *        (--groups: partial dispatch of the bottom-left GX x GY workgroups of the full-size images;
+ *         --crop: write only that window of the three surfaces)
  *        job.bin = "RTJOB1" file written by tests/golden/make_golden.py (layout below).
  *        Writes <out_prefix>.color.f32 / .pos.f32 / .normal.f32  (W*H*4 float each,
  *        row 0 = bottom row, GL origin) and prints one JSON line with timings.
@@ -312,12 +315,14 @@ static int cmp_double(const void *a, const void *b) {
 
 /* ------------------------------------------------------------------ render mode */
 static int mode_render(int argc, char **argv) {
-    if (argc < 5) { fprintf(stderr, "usage: render <glsl> <job.bin> <out_prefix> [--repeat N] [--shipped-dispatch]\n"); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: render <glsl> <job.bin> <out_prefix> [--repeat N] [--shipped-dispatch] [--groups GX GY] [--crop X0 Y0 W H]\n"); return 2; }
     const char *glsl_path = argv[2], *job_path = argv[3], *prefix = argv[4];
-    int repeat = 1, shipped = 0;
+    int repeat = 1, shipped = 0, groupsX = 0, groupsY = 0, crop[4] = {0, 0, 0, 0};
     for (int i = 5; i < argc; i++) {
         if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--shipped-dispatch")) shipped = 1;
+        else if (!strcmp(argv[i], "--groups") && i + 2 < argc) { groupsX = atoi(argv[++i]); groupsY = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--crop") && i + 4 < argc) { for (int k = 0; k < 4; k++) crop[k] = atoi(argv[++i]); }
     }
     char *src0 = read_file(glsl_path, NULL);
     if (!src0) return EXIT_SKIP; /* no reference shader here (e.g. on the GPU box) */
@@ -412,6 +417,11 @@ static int mode_render(int argc, char **argv) {
 
     GLuint gx = shipped ? (GLuint)((W + 15) / 16) : (GLuint)((W + 31) / 32);
     GLuint gy = shipped ? (GLuint)((H + 15) / 16) : (GLuint)((H + 31) / 32);
+    /* --groups: a PARTIAL dispatch of the full-size images.  GL compute has no dispatch offset, but the
+     * group count is free: groups (0..GX-1, 0..GY-1) are exactly the invocations the full dispatch runs
+     * for those pixels (gl_GlobalInvocationID and imageSize() are unchanged), the rest stays untouched.
+     * Used to pin C5 at its real 7680x4320 size in minutes instead of hours. */
+    if (groupsX > 0 && groupsY > 0) { if ((GLuint)groupsX < gx) gx = (GLuint)groupsX; if ((GLuint)groupsY < gy) gy = (GLuint)groupsY; }
 
     /* first dispatch includes the llvmpipe JIT; timed dispatches follow */
     double t0 = now_s();
@@ -446,7 +456,15 @@ static int mode_render(int argc, char **argv) {
         p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, buf);
         gl_check("readback");
         snprintf(path, sizeof path, "%s.%s.f32", prefix, suffix[i]);
-        if (write_file(path, buf, npx * 4 * sizeof(float))) return 5;
+        if (crop[2] > 0 && crop[3] > 0) {      /* --crop: write only the window (rows of W floats*4) */
+            if (crop[0] < 0 || crop[1] < 0 || crop[0] + crop[2] > W || crop[1] + crop[3] > H) { fprintf(stderr, "bad crop\n"); return 2; }
+            float *win = malloc((size_t)crop[2] * crop[3] * 4 * sizeof(float));
+            for (int y = 0; y < crop[3]; y++)
+                memcpy(win + (size_t)y * crop[2] * 4, buf + ((size_t)(crop[1] + y) * W + crop[0]) * 4, (size_t)crop[2] * 4 * sizeof(float));
+            int rc = write_file(path, win, (size_t)crop[2] * crop[3] * 4 * sizeof(float));
+            free(win);
+            if (rc) return 5;
+        } else if (write_file(path, buf, npx * 4 * sizeof(float))) return 5;
     }
     printf("{\"renderer\": \"%s\", \"version\": \"%s\", \"width\": %d, \"height\": %d, "
            "\"groups\": [%u, %u], \"shipped_dispatch\": %d, \"compile_s\": %.6f, "

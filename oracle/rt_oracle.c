@@ -10,6 +10,7 @@
 #include "rt_oracle.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -38,7 +39,7 @@ static inline v3 cross3(v3 a, v3 b) {
     return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 /* mix(a,b,t).  Mesa lowers the built-in context-dependently (nir_lower_flrp); probed bitwise
- * on llvmpipe in the two shapes the shader uses (tests/test_reference_probes.py):
+ * on llvmpipe in the two shapes the shader uses (tests/test_oracle_units.py, fixture tests/golden/probes.npz):
  *   - all-variable operands, t used by no other mix  ->  a + t*(b-a)        (:562)
  *   - constant first operand (vec3(0.04))             ->  a*(1-t) + b*t      (:240) */
 static inline v3 mix3_fast(v3 a, v3 b, float t) { return add3(a, scale3(sub3(b, a), t)); }
@@ -55,52 +56,135 @@ static inline v3 refract3(v3 I, v3 N, float eta) {
 static inline float fract1(float x) { return x - floorf(x); }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 /* pow(x, 5.0) (:222, :241).  llvmpipe evaluates exp2(5*log2(x)): NaN for x < 0 (GLSL leaves
- * pow undefined there; probed with gl_harness probe mode, tests/test_reference_probes.py),
+ * pow undefined there; probed with gl_harness probe mode, tests/test_oracle_units.py, fixture tests/golden/probes.npz),
  * 0 for x = 0, and for x > 0 a value within 1.3e-6 rel of the true power.  The restatement
  * uses the exact-product form (<= 2 ulp from the true power), which the HIP kernel evaluates
- * with the same three multiplies, so the two agree bit for bit. */
+ * with the same three multiplies, so the two agree bit for bit.
+ * DIAGNOSTIC (orc_params.reserved0 bit 0, tests only): use mesa_pow5f below -- llvmpipe's own polynomial
+ * pow, restated bit for bit -- instead; with it gColor equals the reference fixtures bit for bit as well,
+ * which proves that the exact-product pow is the ONLY arithmetic difference left against the reference. */
+static int g_mesa_pow = 0;
+static inline float mesa_pow5f(float x);
 static inline float pow5(float x) {
+    if (g_mesa_pow) return mesa_pow5f(x);
     if (x < 0.0f) return NAN;
     float x2 = x * x;
     return (x2 * x2) * x;
 }
 
-/* Deterministic sin / exp: the only two transcendentals evaluated per pixel (random() :274,
- * exp() :334).  Any <= 1-ulp implementation is within the 1e-4 tolerance of the reference's
- * own polynomial; this one is written with IEEE double +,* only so that the
- * oracle and the HIP kernel (rt_kernels.hip: det_sinf/det_expf) produce identical bits. */
-static inline float det_sinf(float xf) {
-    double x = (double)xf;
-    if (!(fabs(x) < 1.0e9)) return xf - xf; /* inf/NaN -> NaN; never reached by the path */
-    double kd = rint(x * 0.63661977236758134308);
-    long long k = (long long)kd;
-    /* fdlibm's two-term Cody-Waite split: kd*pio2_1 is exact for |kd| < 2^20 (|x| < 1.6e6) */
-    double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
-    double r2 = r * r;
-    double s = r + r * (r2 * (-1.66666666666666324348e-01 + r2 * (8.33333333332248946124e-03 + r2 * (-1.98412698298579493134e-04 +
-               r2 * (2.75573137070700676789e-06 + r2 * (-2.50507602534068634195e-08 + r2 * 1.58969099521155010221e-10))))));
-    double c = 1.0 + r2 * (-0.5 + r2 * (4.16666666666666019037e-02 + r2 * (-1.38888888888741095749e-03 +
-               r2 * (2.48015872894767294178e-05 + r2 * (-2.75573143513906633035e-07 + r2 * 2.08757232129817482790e-09)))));
-    double v = (k & 1) ? c : s;
-    if (k & 2) v = -v;
-    return (float)v;
+/* llvmpipe's log2 / exp2 (gallivm lp_build_log2_approx, lp_build_exp2) -- restated from the published algorithm:
+ *   log2(x) = y*P(y*y) + exponent,  y = (m-1)/(m+1), m = mantissa in [1,2), P of degree 4;
+ *   exp2(x) = 2^floor(x) * Q(x - floor(x)), Q of degree 5, x clamped to [-126.99999, 128];
+ * polynomials by gallivm's even/odd Horner split (lp_build_polynomial), every multiply-add FUSED (llvm.fmuladd on
+ * this FMA3 host).  The coefficient values are those of the installed Mesa 23.2.1 (read from the library's
+ * constant tables, they are Mesa's published minimax fits).  pow(x,y) = exp2(log2(x)*y) and exp(x) =
+ * exp2(x*fl(log2 e)) as NIR lowers them.  Pinned BITWISE against llvmpipe (tests/golden/trig.npz, 2^18 arguments:
+ * log2, exp2, exp, pow(x,5) 100 % equal). */
+static inline float mesa_poly(float x, const float *c, int n) {
+    float x2 = x * x, even = 0.0f, odd = 0.0f;
+    int he = 0, ho = 0;
+    for (int i = n; i--;) {
+        if (i % 2 == 0) { even = he ? fmaf(x2, even, c[i]) : c[i]; he = 1; }
+        else            { odd = ho ? fmaf(x2, odd, c[i]) : c[i]; ho = 1; }
+    }
+    return ho ? fmaf(odd, x, even) : even;
 }
+static inline float mesa_log2f(float x) {
+    static const float P[5] = {2.88539009343309178325f, 0.961791550404184197881f, 0.577440339438736392009f,
+                               0.403343858251329912514f, 0.406718052498846252698f};
+    uint32_t i;
+    memcpy(&i, &x, 4);
+    float logexp = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
+    uint32_t mi = (i & 0x007fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &mi, 4);
+    float y = (m - 1.0f) / (m + 1.0f);
+    float res = fmaf(y, mesa_poly(y * y, P, 5), logexp);
+    if (x >= INFINITY) res = INFINITY;
+    if (x == 0.0f) res = -INFINITY;
+    if (!(x >= 0.0f)) res = NAN;      /* negative or NaN */
+    return res;
+}
+static inline float mesa_exp2f(float x) {
+    static const float Q[6] = {1.0f, 0.693153073200168932794f, 0.240153617044375388211f, 0.0558263180532956664775f,
+                               0.00898934009049466391101f, 0.00187757667519147912699f};
+    if (x != x) return x;
+    x = fmaxf(-126.99999f, fminf(128.0f, x));
+    float ip = floorf(x), fp = x - ip;
+    uint32_t eb = (uint32_t)((int32_t)ip + 127) << 23;
+    float e;
+    memcpy(&e, &eb, 4);
+    return e * mesa_poly(fp, Q, 6);
+}
+/* lp_build_pow: exp2(log2(x)*y), then 0 where x == 0 by an UNORDERED compare (true for NaN too: pow(NaN, 5) = 0) */
+static inline float mesa_pow5f(float x) { return (x == 0.0f || x != x) ? 0.0f : mesa_exp2f(mesa_log2f(x) * 5.0f); }
+static inline float mesa_expf(float x) { return mesa_exp2f(x * 1.44269504088896340736f); }
 
-static inline float det_expf(float xf) {
-    double x = (double)xf;
-    if (x != x) return xf;
-    if (x > 89.0) return INFINITY;
-    if (x < -104.0) return 0.0f;
-    double kd = rint(x * 1.44269504088896338700e+00);
-    double r = (x - kd * 6.93147180369123816490e-01) - kd * 1.90821492927058770002e-10;
-    double p = 1.0 + r * (1.0 + r * (0.5 + r * (1.66666666666666666667e-01 + r * (4.16666666666666666667e-02 +
-               r * (8.33333333333333333333e-03 + r * (1.38888888888888888889e-03 + r * (1.98412698412698412698e-04 +
-               r * (2.48015873015873015873e-05 + r * (2.75573192239858906526e-06 + r * 2.75573192239858906526e-07)))))))));
-    long long k = (long long)kd;
-    unsigned long long bits = (unsigned long long)(k + 1023) << 52;
-    double sc;
-    memcpy(&sc, &bits, 8);
-    return (float)(p * sc);
+/* sin / cos / tan as the reference's GL evaluates them.  Mesa's GLSL front end defines tan(x) as
+ * sin(x)/cos(x) and llvmpipe (gallivm lp_build_sin_or_cos, a port of the cephes / sse_mathfun single-precision
+ * sincos) evaluates both with: |x| scaled by 4/pi, j = (int(y)+1) & ~1, a three-constant Cody-Waite reduction
+ * and two degree-3 polynomials in z = r*r -- with FUSED multiply-adds exactly where gallivm emits llvm.fmuladd
+ * (this host has FMA3; everything else is separate mul / add), the result clamped to [-1, 1] and NaN for a
+ * non-finite argument.  Restated from that published algorithm and pinned BITWISE against llvmpipe itself
+ * (tests/golden/trig.npz: 2^20 arguments incl. |x| up to 1e6, multiples of pi/2, denormals, inf/NaN: 100 %
+ * equal for sin, cos and tan; tests/test_oracle_units.py).  Exact for |x| < 1.6e9 (beyond, int(y) overflows).
+ * Used for tan(radians(fov)*0.5) (:209), cosineWeightedHemisphere's cos/sin(phi) (:296-298) and random()'s
+ * sin (:274), so the camera rays, the bounce samples and the Russian-roulette decisions are the reference's
+ * own, bit for bit.  The HIP side restates the same algorithm (rt_abi.cpp host, rt_kernels.hip device). */
+static inline float mesa_sincosf(float a, int want_cos) {
+    uint32_t ai;
+    memcpy(&ai, &a, 4);
+    uint32_t xi = ai & 0x7fffffffu;
+    float x;
+    memcpy(&x, &xi, 4);
+    float y = x * 1.27323954473516f;                       /* 4/pi */
+    int32_t j = (fabsf(y) < 2147483648.0f) ? (int32_t)y : INT32_MIN;   /* cvttps2dq */
+    int32_t jadd = (int32_t)((uint32_t)j + 1u);
+    int32_t jand = jadd & ~1;
+    float y2 = (float)jand;
+    int32_t e2 = want_cos ? (int32_t)((uint32_t)jand - 2u) : jand;
+    uint32_t sign = want_cos ? (((uint32_t)(4 & ~e2)) << 29) : ((ai ^ ((uint32_t)jadd << 29)) & 0x80000000u);
+    int use_sin_poly = (e2 & 2) == 0;
+    float r = fmaf(y2, -0.78515625f, x);
+    r = fmaf(y2, -2.4187564849853515625e-4f, r);
+    r = fmaf(y2, -3.77489497744594108e-8f, r);
+    float z = r * r;
+    float c = fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    c = fmaf(c, z, 4.166664568298827E-002f);
+    c = (c * z) * z;
+    c = (c - z * 0.5f) + 1.0f;
+    float s_ = fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    s_ = fmaf(s_, z, -1.6666654611E-1f);
+    s_ = fmaf(s_ * z, r, r);
+    float v = use_sin_poly ? s_ : c;
+    uint32_t vi;
+    memcpy(&vi, &v, 4);
+    vi ^= sign;
+    memcpy(&v, &vi, 4);
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    if (!(fabsf(a) < INFINITY)) v = NAN;
+    return v;
+}
+static inline float mesa_sinf(float a) { return mesa_sincosf(a, 0); }
+static inline float mesa_cosf(float a) { return mesa_sincosf(a, 1); }
+static inline float mesa_tanf(float a) { return mesa_sincosf(a, 0) / mesa_sincosf(a, 1); }
+
+/* test hook (tests/test_oracle_units.py): out[3i..3i+2] = sin, cos, tan of in[i] */
+void orc_mesa_trig(const float *in, float *out, int n) {
+    for (int i = 0; i < n; i++) {
+        out[3 * i] = mesa_sinf(in[i]);
+        out[3 * i + 1] = mesa_cosf(in[i]);
+        out[3 * i + 2] = mesa_tanf(in[i]);
+    }
+}
+/* test hook: out[4i..4i+3] = log2, exp2, pow(x,5), exp of in[i] */
+void orc_mesa_explog(const float *in, float *out, int n) {
+    for (int i = 0; i < n; i++) {
+        out[4 * i] = mesa_log2f(in[i]);
+        out[4 * i + 1] = mesa_exp2f(in[i]);
+        out[4 * i + 2] = mesa_pow5f(in[i]);
+        out[4 * i + 3] = mesa_expf(in[i]);
+    }
 }
 
 /* ------------------------------------------------------------------ scene records */
@@ -355,7 +439,7 @@ static v3 cosineWeightedHemisphere(float rx, float ry, v3 n) {
     float phi = 2.0f * PI_F * rx;
     float cosTheta = sqrtf(ry);
     float sinTheta = sqrtf(1.0f - ry);
-    v3 h = V3(sinTheta * cosf(phi), cosTheta, sinTheta * sinf(phi));
+    v3 h = V3(sinTheta * mesa_cosf(phi), cosTheta, sinTheta * mesa_sinf(phi));
     v3 tangent = normalize3(cross3(n, V3(0, 1, 1)));
     v3 bitangent = cross3(n, tangent);
     return normalize3(add3(add3(scale3(tangent, h.x), scale3(bitangent, h.z)), scale3(n, h.y)));
@@ -364,7 +448,7 @@ static v3 cosineWeightedHemisphere(float rx, float ry, v3 n) {
 /* random  :273-275 (vec2 dot: a.y*b.y + a.x*b.x, same z->y->x order as vec3) */
 static float random2(float sx, float sy) {
     float d = sy * 78.233f + sx * 12.9898f;
-    return fract1(det_sinf(d) * 43758.5453123f);
+    return fract1(mesa_sinf(d) * 43758.5453123f);
 }
 
 /* fresnelSchlick  :220-223; pow(x,2.0) = x*x (A.3) */
@@ -464,7 +548,7 @@ static v3 computeSSS(Ctx *c, v3 P, v3 N, const Mat *m) {
         r.direction = cosineWeightedHemisphere(rx, ry, N);
         Mat tm; v3 tn; float t;
         if (intersectObjects(c, &r, &tm, &tn, &t)) {
-            float att = det_expf(-t / m->scatterDistance);
+            float att = mesa_expf(-t / m->scatterDistance);
             sss = add3(sss, scale3(tm.albedo, att));
         }
     }
@@ -526,11 +610,7 @@ static void generateCameraRay(const Ctx *c, Ray *ray, float jx, float jy) {
     ux = ux * 2.0f - 1.0f;
     uy = uy * 2.0f - 1.0f;
     float aspect = (float)p->width / (float)p->height;
-    float tanFov = tanf((p->fovDeg * 0.017453292519943295f) * 0.5f);
-    /* test-only knob: reserved0 != 0 carries the bit pattern of tan(radians(fov)*0.5) as
-     * evaluated by another implementation (e.g. llvmpipe's polynomial, obtained with the
-     * harness' probe mode) so that the remaining arithmetic can be compared bit-for-bit. */
-    if (p->reserved0 != 0) memcpy(&tanFov, &p->reserved0, 4);
+    float tanFov = mesa_tanf((p->fovDeg * 0.017453292519943295f) * 0.5f);   /* radians(x) = x*fl(pi/180), A.3 */
     ux *= aspect * tanFov * p->focalLength;
     uy *= tanFov * p->focalLength;
     v3 cd = V3(p->camDir[0], p->camDir[1], p->camDir[2]);
@@ -612,6 +692,7 @@ int orc_render(const void *objects, int nObj, const void *lights, int nLt, const
     for (int i = 0; i < nObj; i++) decode_object((const uint8_t *)objects + (size_t)i * 176, &objs[i]);
     for (int i = 0; i < nLt; i++) decode_light((const uint8_t *)lights + (size_t)i * 96, &lts[i]);
     uint64_t total = 0;
+    g_mesa_pow = p->reserved0 & 1;      /* diagnostic: llvmpipe's polynomial pow (see pow5) */
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else

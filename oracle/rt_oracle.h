@@ -37,7 +37,7 @@ typedef struct orc_params {
      * ((ly / stripRows) * stripCount + stripIndex) * stripRows + ly % stripRows.
      * stripCount = 1, stripIndex = 0 is the identity. */
     int32_t stripRows, stripCount, stripIndex;
-    int32_t reserved0;    /* test-only knob, see orc_render */
+    int32_t reserved0;    /* unused (was a test-only tan override before mesa_tanf restated llvmpipe's tan) */
     /* unequal strips: stripCycleRows > 0 -> global row (ly / stripRows) * stripCycleRows +
      * stripOffsetRows + ly % stripRows (stripCount / stripIndex ignored) */
     int32_t stripCycleRows, stripOffsetRows;

@@ -33,21 +33,35 @@ def main(src, prefix):
     res = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in pmc.items()}
     json.dump(res, open(prefix + "_pmc.json", "w"), indent=1, sort_keys=True)
     print("wrote", prefix + "_kernel_stats.csv", prefix + "_pmc.json")
-    # HBM traffic of the dominant render kernel, per launch, for bench.py's roofline.traffic:
-    # (2*FETCH_SIZE + WRITE_SIZE) KB -- MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B
-    # request on gfx950 (exact for wide streaming reads, an upper bound otherwise); WRITE_SIZE exact.
+    # Per-launch counters of the dominant render kernel for bench.py (roofline / hbm_physical):
+    # profiles/kernel_counters.json[cN].  HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KB -- MI355X_MICROARCH.md:
+    # FETCH_SIZE counts 64 B per 128-B request on gfx950 (exact for wide streaming reads, an upper bound
+    # otherwise); WRITE_SIZE exact.  src_hash ties the record to the kernel sources it was measured on.
     cfg = os.environ.get("RT_PROFILE_CFG", "c2")
     if os.environ.get("RT_PROFILE_PROG", "bench.py") != "bench.py":
         return      # a secondary chain was profiled: the render kernel's launches there are not bench.py's workload
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_hash
+        src_hash = kernel_source_hash()
+    except Exception:
+        src_hash = None
     for k, cs in res.items():
-        if ("render_packet_kernel<false" in k or "render_kernel<false" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            tpath = os.path.join(os.path.dirname(prefix), "traffic.json")
+        if ("render_packet_kernel<0" in k or "render_packet_kernel<false" in k or "render_kernel<0" in k) and "SQ_INSTS_VALU" in cs:
+            tpath = os.path.join(os.path.dirname(prefix), "kernel_counters.json")
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-            t[cfg] = {"hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024),
-                      "fetch_size_kb": cs["FETCH_SIZE"]["mean"], "write_size_kb": cs["WRITE_SIZE"]["mean"],
-                      "kernel": k.split("(")[0], "source": os.path.basename(prefix) + "_pmc.json"}
+            rec = {c: v["mean"] for c, v in cs.items()}
+            rec.update({"fetch_size_kb": cs.get("FETCH_SIZE", {}).get("mean"), "write_size_kb": cs.get("WRITE_SIZE", {}).get("mean"),
+                        "kernel": k.split("(")[0], "source": os.path.basename(prefix) + "_pmc.json", "src_hash": src_hash})
+            st = stats.get(k)
+            if st:
+                rec["kernel_avg_us"] = round(st[1] / st[0], 3)
+                rec["kernel_calls"] = st[0]
+            if rec["fetch_size_kb"] is not None and rec["write_size_kb"] is not None:
+                rec["hbm_bytes_per_launch"] = int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024)
+            t[cfg] = rec
             json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
-            print("wrote", tpath)
+            print("wrote", tpath, cfg)
             break
 
 

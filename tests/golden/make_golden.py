@@ -362,6 +362,99 @@ void main(){ uint g=gl_GlobalInvocationID.x; vec3 v=vec3(a[g*3u],a[g*3u+1u],a[g*
     print("  [cubemap] written", flush=True)
 
 
+def make_c5_8k(strip_groups_y=24, column_groups_x=4, win=48):
+    """C5 at its REAL size, 7680x4320 (VERDICT r1 'parity unpinned at 8K'): GL compute has no dispatch offset,
+    but the group count is free -- glDispatchCompute(240, GY, 1) on the full-size images runs exactly the
+    invocations the full dispatch runs for the bottom 32*GY rows (gl_GlobalInvocationID, imageSize() and hence uv
+    and random()'s arguments are those of the 8K frame), and glDispatchCompute(GX, 135, 1) the left 32*GX columns
+    over the whole height (gid.y up to 4319: the large random() arguments).  The fixture keeps `win`-pixel
+    windows cut from the two regions; the raw strips stay in /tmp (tens of MB)."""
+    sc = scenes.make_scene(5, host.generate_aabb)
+    p = sc.params()
+    W, H = p.width, p.height
+    assert (W, H) == (7680, 4320)
+    data = {"objects": np.frombuffer(sc.objects.tobytes(), dtype=np.uint8).copy(),
+            "lights": np.frombuffer(sc.lights.tobytes(), dtype=np.uint8).copy(),
+            "params": params_bytes(p), "tan_bits": np.int32(probe_tan(p.fovDeg)),
+            "frame_count": np.int32(sc.frame_count), "max_ray_depth": np.int32(sc.max_ray_depth)}
+    origins, cols, poss, nrms = [], [], [], []
+    regions = [("strip", (W // 32, strip_groups_y), (0, 0, W, 32 * strip_groups_y)),
+               ("column", (column_groups_x, (H + 31) // 32), (0, 0, 32 * column_groups_x, H))]
+    rng = np.random.default_rng(58)
+    for tag, groups, crop in regions:
+        t = time.time()
+        col, pos, nrm, info = O.run_reference(sc, p, repeat=0, groups=groups, crop=crop)
+        nrm = nrm.astype(np.float16)
+        print(f"  [c5_8k {tag}] groups {groups}: llvmpipe {info['first_dispatch_s']:.1f}s (wall {time.time() - t:.1f}s)", flush=True)
+        np.savez_compressed(f"/tmp/c5_8k_{tag}.npz", color=col, pos=pos, normal=nrm)
+        data[f"{tag}_dispatch_s"] = np.float64(info["first_dispatch_s"])
+        rw, rh = crop[2], crop[3]
+        # windows on a jittered grid over the region; keep those with content first (hits), then fill with the rest
+        nx, ny = max(1, rw // 640), max(1, rh // 360)
+        cand = []
+        for gy_ in range(ny):
+            for gx_ in range(nx):
+                x0 = int(min(rw - win, gx_ * rw / nx + rng.integers(0, max(1, rw // nx - win))))
+                y0 = int(min(rh - win, gy_ * rh / ny + rng.integers(0, max(1, rh // ny - win))))
+                hits = float((pos[y0:y0 + win, x0:x0 + win, 3] == 1).mean())          # all pixels store alpha 1
+                var = float(np.nanstd(col[y0:y0 + win, x0:x0 + win, :3]))
+                cand.append((var, x0, y0))
+        cand.sort(reverse=True)
+        for var, x0, y0 in cand[:14]:
+            origins.append((crop[0] + x0, crop[1] + y0))
+            cols.append(col[y0:y0 + win, x0:x0 + win])
+            poss.append(pos[y0:y0 + win, x0:x0 + win])
+            nrms.append(nrm[y0:y0 + win, x0:x0 + win])
+    data["win8k_origins"] = np.array(origins, dtype=np.int32)
+    data["win8k_color"], data["win8k_pos"], data["win8k_normal"] = np.stack(cols), np.stack(poss), np.stack(nrms)
+    data["renderer"] = np.array(info["renderer"] + " / " + info["version"])
+    np.savez_compressed(os.path.join(OUT, "c5_8k.npz"), **data)
+    print(f"  [c5_8k] {len(origins)} windows of {win}x{win} written", flush=True)
+
+
+def make_trig():
+    """llvmpipe's sin / cos / tan / log2 / exp2 / pow(x,5) / exp, bitwise (trig.npz).  Pins oracle/rt_oracle.c's
+    mesa_* restatements (gallivm's cephes-style sincos with fused multiply-adds, polynomial log2 / exp2): the
+    camera's tan(radians(fov)*0.5), cosineWeightedHemisphere's cos/sin(phi), random()'s sin(large), SSS's exp."""
+    rng = np.random.default_rng(7)
+    n = 1 << 16
+    q = n // 8
+    x = np.concatenate([rng.uniform(-8, 8, 2 * q), rng.uniform(-1e6, 1e6, 2 * q),
+                        (np.arange(q) % 4096 - 2048) * np.float32(np.pi / 2) + rng.normal(0, 1e-3, q),
+                        np.radians(np.linspace(0.01, 179.99, q)) * 0.5, rng.uniform(0, 1.6, q),
+                        10.0 ** rng.uniform(-30, 9.0, q)]).astype(np.float32)
+    x[:6] = [0, -0.0, np.inf, -np.inf, np.nan, 1e9]
+    glsl = """#version 430 core
+layout(local_size_x = 64) in;
+layout(std430, binding = 0) buffer In { float xin[]; };
+layout(std430, binding = 1) buffer Out { float xout[]; };
+void main(){ uint i=gl_GlobalInvocationID.x; float a=xin[i]; xout[3u*i]=sin(a); xout[3u*i+1u]=cos(a); xout[3u*i+2u]=tan(a); }
+"""
+    out = {"trig_in": x, "trig_out": O.run_probe(glsl, x, np.float32, 3 * n, n // 64).reshape(n, 3)}
+    # the exact expression of generateCameraRay (:209) over fov in (0, 180)
+    fov = np.concatenate([np.linspace(0.05, 179.95, n - 64), np.array([20, 30, 45, 60, 75, 90, 100, 120] * 8)]).astype(np.float32)
+    glsl = """#version 430 core
+layout(local_size_x = 64) in;
+layout(std430, binding = 0) buffer In { float xin[]; };
+layout(std430, binding = 1) buffer Out { float xout[]; };
+void main(){ uint i=gl_GlobalInvocationID.x; xout[i]=tan(radians(xin[i]) * 0.5); }
+"""
+    out["fov_in"] = fov
+    out["fov_tan"] = O.run_probe(glsl, fov, np.float32, n, n // 64)
+    y = np.concatenate([rng.uniform(0, 1, n // 2), rng.uniform(-20, 20, n // 4), 10.0 ** rng.uniform(-20, 10, n // 4)]).astype(np.float32)
+    y[:6] = [0, -0.0, np.inf, -np.inf, np.nan, 1.0]
+    glsl = """#version 430 core
+layout(local_size_x = 64) in;
+layout(std430, binding = 0) buffer In { float xin[]; };
+layout(std430, binding = 1) buffer Out { float xout[]; };
+void main(){ uint i=gl_GlobalInvocationID.x; float a=xin[i]; xout[4u*i]=log2(a); xout[4u*i+1u]=exp2(a); xout[4u*i+2u]=pow(a,5.0); xout[4u*i+3u]=exp(a); }
+"""
+    out["explog_in"] = y
+    out["explog_out"] = O.run_probe(glsl, y, np.float32, 4 * n, n // 64).reshape(n, 4)
+    np.savez_compressed(os.path.join(OUT, "trig.npz"), **out)
+    print("  [trig] written", flush=True)
+
+
 def make_surface_probes():
     """rgba16f imageStore rounding + cubemap sampling through a render-mode job with a tiny
     custom shader is not needed: both are exercised by the c5/nan fixtures.  (Kept as a hook.)"""
@@ -374,7 +467,7 @@ def main():
     args = ap.parse_args()
     if not O.harness_available():
         sys.exit("gl_harness or /root/reference is not available: goldens can only be generated in the build container")
-    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom", "ssao", "cubemap"]
+    names = [s for s in args.only.split(",") if s] or list(PLAN) + ["probes", "taa", "bloom", "ssao", "cubemap", "c5_8k", "trig"]
     for nme in names:
         print(f"== {nme}", flush=True)
         if nme == "probes":
@@ -387,6 +480,10 @@ def main():
             make_ssao()
         elif nme == "cubemap":
             make_cubemap()
+        elif nme == "c5_8k":
+            make_c5_8k()
+        elif nme == "trig":
+            make_trig()
         else:
             make_config(nme, args.skip_fullres)
 

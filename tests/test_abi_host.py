@@ -11,6 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import load_golden
 from opengl_raytracing_amd import layout as L
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -197,3 +198,22 @@ def test_strip_bookkeeping(host):
         for y in (0, h // 2, h - 1):
             r, ly = divmod(idx[y], plan.max_local_rows)
             assert plan.global_row(r, ly) == y
+
+
+def test_mesa_trig_host(host):
+    """csrc/rt_mesa_math.h (host instantiation, the one rt_abi.cpp uses for tan(radians(fov)/2) and the bounce
+    sample's cos / sin) against the llvmpipe fixture directly: sin, cos, tan and exp BIT FOR BIT.  The device
+    instantiation of the same header is pinned through the rendered pixels by the GPU parity tests."""
+    g = load_golden("trig")
+    x, ref = g["trig_in"], g["trig_out"]
+    got = host.mesa_math(x)
+    ok = (np.abs(x) < 1.6e9) | ~np.isfinite(x)
+    for k, name in enumerate(("sin", "cos", "tan")):
+        eq = (got[:, k].view(np.uint32) == ref[:, k].view(np.uint32)) | (np.isnan(got[:, k]) & np.isnan(ref[:, k]))
+        assert eq[ok].all(), f"{name}: {int((~eq[ok]).sum())} differ"
+    y, refe = g["explog_in"], g["explog_out"][:, 3]
+    gote = host.mesa_math(y)[:, 3]
+    eq = (gote.view(np.uint32) == refe.view(np.uint32)) | (np.isnan(gote) & np.isnan(refe))
+    assert eq.all(), f"exp: {int((~eq).sum())} differ"
+    half = (g["fov_in"] * np.float32(0.017453292519943295)) * np.float32(0.5)
+    assert (host.mesa_math(half)[:, 2].view(np.uint32) == g["fov_tan"].view(np.uint32)).all()

@@ -5,9 +5,9 @@ Bars:
 * HIP vs oracle: BIT-EXACT on all three surfaces and an identical ray count -- both evaluate
   the same fp32 expression tree (no FMA contraction, IEEE div/sqrt, shared deterministic
   sin/exp/pow5), so any difference is a kernel bug.
-* HIP vs reference fixture (llvmpipe run of the reference GLSL): gColor within 1e-4 relative on
-  >= 99 % of pixels (1-ulp tan difference amplified by multi-bounce paths, see
-  test_oracle_golden.py); the oracle's own gate against the fixture is tighter and CPU-side.
+* HIP vs reference fixture (llvmpipe runs of the reference GLSL, low-res frames, full-resolution windows and
+  7680x4320 windows): gPosition / gNormal BIT-EXACT, gColor within 1e-4 relative on >= 99.9 % of pixels
+  (REF_GATES below; the host and the kernel evaluate tan / sin / cos / exp as the reference's GL does).
 """
 import ctypes
 
@@ -83,18 +83,83 @@ def test_c2_full_frame_properties(tracer, host, oracle):
     assert (col[..., 3] == 1).all() and (pos[..., 3] == 1).all() and (nrm[..., 3] == np.float16(1)).all()
 
 
+# HIP vs the REFERENCE's own pixels (llvmpipe runs of the unmodified GLSL, tests/golden/*.npz), directly -- not through
+# the oracle.  The host side evaluates tan / cos / sin and the kernel random()'s sin and SSS's exp exactly as the
+# reference's GL does (csrc/rt_mesa_math.h), so the geometry surfaces must be the reference's BIT FOR BIT and gColor
+# within north_star's 1e-4 (the one arithmetic difference left is pow(x,5): exact product here, exp2(5 log2 x)
+# polynomials on llvmpipe, <= 1.3e-6 apart).  fixture -> (min bit-exact fraction of gPosition and of gNormal,
+# min fraction of gColor pixels within 1e-4 relative).  Measured residue: C3 20 px of 32 400 (NEAREST noise texel at
+# exact texel boundaries), C5 8 px of 14 400 (8th loop iteration, see tests/test_oracle_golden.py).
+REF_GATES = {"c1": (1.0, 1.0), "c2": (1.0, 1.0), "c3": (0.999, 0.9999), "c4": (1.0, 0.9999), "c5": (1.0, 0.999), "nan": (1.0, 1.0)}
+
+
+def _frac_exact(a, b):
+    return compare_surface(a, b, rtol=0, atol=0)["exact_frac"]
+
+
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "nan"])
 def test_lowres_frame_against_reference_fixture(tracer, name):
-    """HIP path vs the llvmpipe run of the reference GLSL (committed fixture)."""
+    """Whole low-resolution frame of every config's scene against the reference's pixels."""
     g = load_golden(name)
     sc = GoldenScene(g)
     p = params_from_bytes(g["lowres_params"])
     col, pos, nrm = render_gpu(tracer, sc, p)
+    exact_min, color_min = REF_GATES[name]
+    ep, en = _frac_exact(pos, g["lowres_pos"]), _frac_exact(nrm.astype(np.float32), g["lowres_normal"].astype(np.float32))
     cc = compare_surface(col, g["lowres_color"])
-    gate = {"c1": 0.999, "c2": 0.99, "c3": 0.99, "c4": 0.97, "c5": 0.97, "nan": 0.99}[name]
-    assert cc["pass_frac"] >= gate, f"{name}: gColor pass {cc['pass_frac']:.5f}"
-    cn = compare_surface(nrm.astype(np.float32), g["lowres_normal"].astype(np.float32), rtol=0, atol=1e-3)
-    assert cn["pass_frac"] >= gate - 0.03, f"{name}: gNormal pass {cn['pass_frac']:.5f}"
+    print(f"{name}: HIP vs reference lowres: gPosition exact {ep:.6f} gNormal exact {en:.6f} gColor 1e-4 {cc['pass_frac']:.6f}")
+    assert ep >= exact_min, f"{name}: gPosition bit-exact on {ep:.6f}"
+    assert en >= exact_min, f"{name}: gNormal bit-exact on {en:.6f}"
+    assert cc["pass_frac"] >= color_min, f"{name}: gColor within 1e-4 on {cc['pass_frac']:.6f} ({cc['n_fail']} px)"
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
+def test_fullres_windows_against_reference_fixture(tracer, name):
+    """Eight 32x32 windows cut from the reference's FULL-resolution frame (C2 1080p, C3 / C4 4K; C5: its scene at
+    1080p) -- the HIP path renders just those windows of the full-size image through the ABI's window parameters."""
+    g = load_golden(name)
+    if "win_params" not in g.files:
+        pytest.skip("no full-resolution windows in this fixture")
+    sc = GoldenScene(g)
+    tracer.load(sc)
+    base = params_from_bytes(g["win_params"])
+    exact_min, color_min = REF_GATES[name]
+    n_px = ep = en = okc = 0
+    for k, (x0, y0) in enumerate(g["win_origins"]):
+        p = L.copy_params(base, x0=int(x0), y0=int(y0), regionW=32, regionH=32)
+        tracer.render(p)
+        col, pos, nrm = tracer.readback()
+        n_px += 32 * 32
+        ep += compare_surface(pos, g["win_pos"][k], rtol=0, atol=0)["exact_mask"].sum()
+        en += compare_surface(nrm.astype(np.float32), g["win_normal"][k].astype(np.float32), rtol=0, atol=0)["exact_mask"].sum()
+        okc += compare_surface(col, g["win_color"][k])["ok_mask"].sum()
+    print(f"{name}: HIP vs reference windows: gPosition exact {ep / n_px:.6f} gNormal exact {en / n_px:.6f} gColor 1e-4 {okc / n_px:.6f}")
+    assert ep / n_px >= min(exact_min, 0.9995) and en / n_px >= min(exact_min, 0.9995)
+    assert okc / n_px >= min(color_min, 0.999)
+
+
+def test_c5_at_7680x4320_against_reference_fixture(tracer):
+    """C5 at its REAL size: windows of the reference's 7680x4320 frame (partial dispatches of the unmodified GLSL
+    on the full-size images, tests/golden/make_golden.py make_c5_8k) -- uv depends on imageSize and random() sees
+    arguments up to 7e5 only here (raytracingCs.glsl:200-211, :273-275)."""
+    g = load_golden("c5_8k")
+    sc = GoldenScene(dict(objects=g["objects"], lights=g["lights"], frame_count=g["frame_count"], has_noise=0, has_skybox=1))
+    tracer.load(sc)
+    base = params_from_bytes(g["params"])
+    assert (base.width, base.height) == (7680, 4320)
+    win = g["win8k_color"].shape[1]
+    n_px = ep = en = okc = 0
+    for k, (x0, y0) in enumerate(g["win8k_origins"]):
+        p = L.copy_params(base, x0=int(x0), y0=int(y0), regionW=win, regionH=win)
+        tracer.render(p)
+        col, pos, nrm = tracer.readback()
+        n_px += win * win
+        ep += compare_surface(pos, g["win8k_pos"][k], rtol=0, atol=0)["exact_mask"].sum()
+        en += compare_surface(nrm.astype(np.float32), g["win8k_normal"][k].astype(np.float32), rtol=0, atol=0)["exact_mask"].sum()
+        okc += compare_surface(col, g["win8k_color"][k])["ok_mask"].sum()
+    print(f"c5 8K: HIP vs reference: gPosition exact {ep / n_px:.6f} gNormal exact {en / n_px:.6f} gColor 1e-4 {okc / n_px:.6f}")
+    assert ep / n_px >= 0.999 and en / n_px >= 0.999
+    assert okc / n_px >= 0.995
 
 
 def test_nan_and_ub_corners_match_oracle(tracer, host, oracle):
@@ -393,3 +458,66 @@ def test_frames_in_flight_on_several_streams(tracer, host):
             for got, want in zip((c, q, n), ref):
                 assert bits_equal(got.cpu().numpy(), want), f"frame {k}"
     torch.cuda.synchronize()
+
+
+def test_first_frames_of_a_new_geometry_on_three_streams(host):
+    """the tile order is adopted per CONTEXT but streams are not ordered with each other, so on a
+    never-seen geometry frame 2 (third stream) used to read an order buffer only frame 1's stream had waited for.
+    A fresh context, three streams, a geometry it has never rendered, zeroed targets: frames 0..7 must each cover
+    every tile exactly once (bit-exact vs a single-stream render).  Repeated for several geometries so that the
+    order buffers also carry a stale permutation of the PREVIOUS geometry when the next one starts."""
+    import torch
+    sc = scenes.make_scene(2, host.generate_aabb)
+    with host.RayTracer(0) as rt:
+        rt.load(sc)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        for (w, h) in [(640, 360), (320, 200), (648, 368), (640, 360)]:
+            p = sc.params(width=w, height=h)
+            with host.RayTracer(0) as ref_rt:
+                ref_rt.load(sc)
+                ref_rt.set_variant(0x101)        # packet kernel, raster order: no feedback state involved
+                ref_rt.render(p)
+                ref = ref_rt.readback()
+            bufs = [(torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"), torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"),
+                     torch.zeros((h, w, 4), dtype=torch.float16, device="cuda")) for _ in range(8)]
+            torch.cuda.synchronize()
+            for k in range(8):                   # host runs ahead: nothing synchronises between the launches
+                c, q, n = bufs[k]
+                rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=streams[k % 3].cuda_stream)
+            torch.cuda.synchronize()
+            for k in range(8):
+                for got, want in zip(bufs[k], ref):
+                    assert bits_equal(got.cpu().numpy(), want), f"{w}x{h} frame {k}"
+
+
+def test_scene_updates_between_frames_in_flight_on_three_streams(host, oracle):
+    """the reference re-uploads its SSBOs every frame (ImGUIManager.cpp:202, :338), so rt_set_scene
+    alternates with frames that are still in flight on several caller streams.  Each frame must be rendered from
+    the scene that was current when it was issued: rt_set_scene orders the rewrite of the device scene behind the
+    last launch of EVERY stream, not only the most recent one."""
+    import torch
+    base = scenes.make_scene(2, host.generate_aabb)
+    w, h = 480, 270
+    p = base.params(width=w, height=h)
+    variants = []
+    for k in range(4):
+        sc = scenes.make_scene(2, host.generate_aabb)
+        sc.objects["position"][:, 0] += 0.35 * k
+        sc.objects["position"][:, 1] += 0.1 * k
+        host.generate_aabb(sc.objects)
+        variants.append((sc, oracle.render(sc, p)))
+    with host.RayTracer(0) as rt:
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        n_frames = 24
+        bufs = [(torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"), torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"),
+                 torch.zeros((h, w, 4), dtype=torch.float16, device="cuda")) for _ in range(n_frames)]
+        torch.cuda.synchronize()
+        for k in range(n_frames):
+            sc, _ = variants[k % 4]
+            rt.set_scene(sc.objects, sc.lights)          # while frames k-1, k-2 are still running on other streams
+            c, q, n = bufs[k]
+            rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr(), stream=streams[k % 3].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(n_frames):
+            want = variants[k % 4][1]
+            assert_bit_exact(tuple(t.cpu().numpy() for t in bufs[k]), want, f"frame {k} (scene {k % 4})")

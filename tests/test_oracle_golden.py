@@ -2,17 +2,19 @@
 /root/reference/shader/raytracingCs.glsl executed unmodified on Mesa llvmpipe, committed as
 fixtures by tests/golden/make_golden.py.  CPU only.
 
-Two gates per fixture:
+The oracle restates llvmpipe's own sin / cos / tan (tests/test_oracle_units.py pins them bitwise), so the camera
+scale tan(radians(fov)*0.5), the per-depth bounce sample and the Russian-roulette hash are the reference's values
+and NO test-only knob is involved any more.  Gates per fixture:
 
-* "same tan": the restatement is given llvmpipe's own value of tan(radians(fov)*0.5) (stored
-  in the fixture).  Everything geometric is then the same IEEE arithmetic in the same order,
-  so gPosition / gNormal must match BIT FOR BIT and gColor within 1e-4 relative (the only
-  remaining difference is llvmpipe's polynomial pow(x,5) vs the exact product, <= 1.3e-6).
-  Depth-8 fixtures allow a handful of Russian-roulette flips (random() hinges on
-  sin(large)*43758, A.1#18).
-* "own tan": the restatement as shipped (libm tanf, 1 ulp from llvmpipe's at fov 45).  That
-  single ulp perturbs every camera ray; multi-bounce paths over curved mirrors amplify it,
-  so the gate is statistical: >= 99 % of pixels within 1e-4 on gColor.
+* gPosition / gNormal BIT FOR BIT (everything geometric is the same IEEE arithmetic in the same order);
+* gColor within 1e-4 relative: the only arithmetic difference left is pow(x,5) -- exact product here and in the
+  HIP kernel, exp2(5 log2 x) polynomials on llvmpipe (<= 1.3e-6 apart);
+* DIAGNOSTIC: with llvmpipe's polynomial pow restated too (orc_params.reserved0 bit 0) gColor is bit-exact as well
+  on >= 99.9 % of pixels (C5, whose paths end in bilinear skybox taps: >= 90 %), which proves the claim above.
+* Known residue, measured and classified: C3 (noise-texture jitter) has 20 of 32 400 px whose gPosition differs
+  (NEAREST texel choice at exact texel boundaries); C5 at depth 8 has 8 of 14 400 px whose colour differs by
+  percents with identical gPosition -- they appear only when MAX_RAY_DEPTH >= 8 (0 px at depth <= 7), always as
+  oracle > reference: llvmpipe evaluates the 8th iteration of the (then no longer fully unrolled) loop differently.
 """
 import numpy as np
 import pytest
@@ -20,21 +22,21 @@ import pytest
 from conftest import GoldenScene, compare_surface, load_golden, params_from_bytes
 from opengl_raytracing_amd import layout as L
 
-# fixture -> (min exact fraction of gPosition/gNormal with the same tan, min gColor pass fraction
-#             with the same tan, min gColor pass fraction with own tan)
+# fixture -> (min exact fraction of gPosition/gNormal, min gColor pass fraction at 1e-4,
+#             min gColor BIT-EXACT fraction with the polynomial-pow diagnostic)
 GATES = {
-    "c1": (1.0, 1.0, 0.999),
-    "c2": (1.0, 0.9999, 0.99),
-    "c3": (0.999, 0.9999, 0.99),
-    "c4": (0.999, 0.999, 0.97),
-    "c5": (0.999, 0.999, 0.97),
-    "nan": (1.0, 0.9999, 0.99),
+    "c1": (1.0, 1.0, 1.0),
+    "c2": (1.0, 1.0, 0.9999),
+    "c3": (0.999, 1.0, 0.999),
+    "c4": (1.0, 1.0, 0.999),
+    "c5": (1.0, 0.999, 0.90),
+    "nan": (1.0, 1.0, 1.0),
 }
 
 
-def render_oracle(oracle, scene, params, tan_bits=0):
+def render_oracle(oracle, scene, params, mesa_pow=False):
     p = L.copy_params(params)
-    p.reserved0 = int(tan_bits)
+    p.reserved0 = 1 if mesa_pow else 0
     return oracle.render(scene, p)
 
 
@@ -43,20 +45,20 @@ def test_lowres_frame_against_reference(oracle, name):
     g = load_golden(name)
     sc = GoldenScene(g)
     p = params_from_bytes(g["lowres_params"])
-    exact_min, color_same_min, color_own_min = GATES[name]
-    col, pos, nrm, rays = render_oracle(oracle, sc, p, g["tan_bits"])
+    exact_min, color_min, color_exact_min = GATES[name]
+    col, pos, nrm, rays = render_oracle(oracle, sc, p)
     cp = compare_surface(pos, g["lowres_pos"], rtol=0, atol=0)
     cn = compare_surface(nrm.astype(np.float32), g["lowres_normal"].astype(np.float32), rtol=0, atol=0)
     cc = compare_surface(col, g["lowres_color"])
     assert cp["exact_frac"] >= exact_min, f"gPosition exact {cp['exact_frac']:.6f}"
     assert cn["exact_frac"] >= exact_min, f"gNormal exact {cn['exact_frac']:.6f}"
-    assert cc["pass_frac"] >= color_same_min, f"gColor pass {cc['pass_frac']:.6f} ({cc['n_fail']} px)"
+    assert cc["pass_frac"] >= color_min, f"gColor pass {cc['pass_frac']:.6f} ({cc['n_fail']} px)"
     # NaN pixels (reference UB corners) must be NaN in both
-    assert (np.isnan(col).any(axis=-1) == np.isnan(g["lowres_color"]).any(axis=-1)).mean() >= color_same_min
-    # as shipped (own tanf)
-    col2, pos2, nrm2, _ = render_oracle(oracle, sc, p, 0)
-    cc2 = compare_surface(col2, g["lowres_color"])
-    assert cc2["pass_frac"] >= color_own_min, f"gColor pass (own tan) {cc2['pass_frac']:.6f}"
+    assert (np.isnan(col).any(axis=-1) == np.isnan(g["lowres_color"]).any(axis=-1)).mean() >= color_min
+    # diagnostic: llvmpipe's polynomial pow restated as well -> gColor bit for bit
+    col2, pos2, nrm2, _ = render_oracle(oracle, sc, p, mesa_pow=True)
+    ce = compare_surface(col2, g["lowres_color"], rtol=0, atol=0)
+    assert ce["exact_frac"] >= color_exact_min, f"gColor exact (polynomial pow) {ce['exact_frac']:.6f}"
     # miss pixels: (0,0,0,1) on all three surfaces
     miss = (g["lowres_pos"][..., :3] == 0).all(axis=-1) & (g["lowres_normal"][..., :3] == 0).all(axis=-1)
     if miss.any():
@@ -74,17 +76,19 @@ def test_fullres_windows_against_reference(oracle, name):
     sc = GoldenScene(g)
     base = params_from_bytes(g["win_params"])
     exact_min, color_same_min, _ = GATES[name]
+    exact_min, color_same_min = min(exact_min, 0.9995), min(color_same_min, 0.9995)
     n_px = n_exact_p = n_exact_n = n_ok_c = 0
     for k, (x0, y0) in enumerate(g["win_origins"]):
         p = L.copy_params(base, x0=int(x0), y0=int(y0), regionW=32, regionH=32)
-        col, pos, nrm, _ = render_oracle(oracle, sc, p, g["tan_bits"])
+        col, pos, nrm, _ = render_oracle(oracle, sc, p)
         n_px += 32 * 32
         n_exact_p += compare_surface(pos, g["win_pos"][k], rtol=0, atol=0)["exact_mask"].sum()
         n_exact_n += compare_surface(nrm.astype(np.float32), g["win_normal"][k].astype(np.float32), rtol=0, atol=0)["exact_mask"].sum()
         n_ok_c += compare_surface(col, g["win_color"][k])["ok_mask"].sum()
-    assert n_exact_p / n_px >= exact_min - 1e-3, f"gPosition exact {n_exact_p / n_px:.6f}"
-    assert n_exact_n / n_px >= exact_min - 1e-3, f"gNormal exact {n_exact_n / n_px:.6f}"
-    assert n_ok_c / n_px >= color_same_min - 1e-3, f"gColor pass {n_ok_c / n_px:.6f}"
+    print(f"{name}: windows gPosition exact {n_exact_p / n_px:.6f} gNormal exact {n_exact_n / n_px:.6f} gColor pass {n_ok_c / n_px:.6f}")
+    assert n_exact_p / n_px >= exact_min, f"gPosition exact {n_exact_p / n_px:.6f}"
+    assert n_exact_n / n_px >= exact_min, f"gNormal exact {n_exact_n / n_px:.6f}"
+    assert n_ok_c / n_px >= color_same_min, f"gColor pass {n_ok_c / n_px:.6f}"
 
 
 def test_window_and_strip_renders_equal_full_frame(oracle):
