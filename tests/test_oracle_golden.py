@@ -115,3 +115,26 @@ def test_window_and_strip_renders_equal_full_frame(oracle):
             else:
                 assert (cs[ly] == 0).all() and (ns[ly].view(np.uint16) == 0).all()
     assert total == rays
+
+
+def test_c5_at_7680x4320_windows_against_reference(oracle):
+    """C5 at its REAL size ('parity unpinned at 8K'): 26 windows of 48x48 cut from the reference's
+    7680x4320 frame -- partial dispatches of the unmodified GLSL on the full-size images (bottom 768 rows, and the
+    left 128 columns over the whole height), so uv (imageSize) and random()'s arguments (gid up to 4319 + depth) are
+    those of the 8K frame (raytracingCs.glsl:200-211, :273-275).  The oracle renders just those windows."""
+    g = load_golden("c5_8k")
+    sc = GoldenScene(dict(objects=g["objects"], lights=g["lights"], frame_count=g["frame_count"], has_noise=0, has_skybox=1))
+    base = params_from_bytes(g["params"])
+    assert (base.width, base.height) == (7680, 4320) and base.maxRayDepth == 8
+    win = g["win8k_color"].shape[1]
+    n_px = ep = en = okc = 0
+    for k, (x0, y0) in enumerate(g["win8k_origins"]):
+        p = L.copy_params(base, x0=int(x0), y0=int(y0), regionW=win, regionH=win)
+        col, pos, nrm, _ = oracle.render(sc, p)
+        n_px += win * win
+        ep += compare_surface(pos, g["win8k_pos"][k], rtol=0, atol=0)["exact_mask"].sum()
+        en += compare_surface(nrm.astype(np.float32), g["win8k_normal"][k].astype(np.float32), rtol=0, atol=0)["exact_mask"].sum()
+        okc += compare_surface(col, g["win8k_color"][k])["ok_mask"].sum()
+    print(f"c5 8K: gPosition exact {ep / n_px:.6f} gNormal exact {en / n_px:.6f} gColor pass {okc / n_px:.6f} ({n_px} px)")
+    assert ep / n_px >= 0.9995 and en / n_px >= 0.9995
+    assert okc / n_px >= 0.999
