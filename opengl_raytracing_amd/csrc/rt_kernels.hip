@@ -21,6 +21,7 @@
 // restatement in oracle/ wherever no transcendental is involved.
 #include "rt_device.h"
 #include "rt_mesa_math.h"
+#include "rt_fastmath.h"
 
 #include <hip/hip_fp16.h>
 
@@ -43,8 +44,8 @@ __device__ __forceinline__ v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ v3 splat(float s) { return V3(s, s, s); }
 // llvmpipe lowering: dot = (z*z + y*y) + x*x
 __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
-__device__ __forceinline__ float length(v3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ __forceinline__ float length(v3 a) { return rtf::sqrt(dot(a, a)); }
+__device__ __forceinline__ v3 normalize(v3 a) { return a * rtf::rcp_sqrt(dot(a, a)); }   // v * (1.0/sqrt(dot)), both steps correctly rounded
 __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
@@ -58,7 +59,7 @@ __device__ __forceinline__ v3 refract(v3 I, v3 N, float eta) {
     float d = dot(N, I);
     float k = 1.0f - eta * (eta * (1.0f - d * d));
     if (k < 0.0f) return V3(0.0f, 0.0f, 0.0f);
-    return I * eta - N * (eta * d + sqrtf(k));
+    return I * eta - N * (eta * d + rtf::sqrt(k));
 }
 __device__ __forceinline__ float fract(float x) { return x - floorf(x); }
 // pow(x, 5.0) (raytracingCs.glsl:222, :241): NaN for x < 0 as on the reference's GL
@@ -135,7 +136,7 @@ __device__ __forceinline__ bool shape_test(const Ray &r, float a, const float4 *
         float c = dot(oc, oc) - h1.w;               // h1.w = radius*radius
         float disc = b * b - 4.0f * a * c;
         if (disc < 0.0f) return false;
-        t = (-b - sqrtf(disc)) / (2.0f * a);
+        t = (-b - rtf::sqrt(disc)) / (2.0f * a);
         return t > 0.0f;
     } else if (type == 1) {
         float4 h2 = h[2], h3 = h[3];
@@ -160,7 +161,8 @@ template <int COUNT>
 __device__ __forceinline__ int trace_closest(const SceneLds &sc, int nObj, const Ray &r, float maxDist,
                                               float &tOut, unsigned &rays) {
     if (COUNT) rays++;
-    v3 inv = V3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    v3 inv;
+    rtf::rcp3(r.d.x, r.d.y, r.d.z, inv.x, inv.y, inv.z);
     float a = dot(r.d, r.d);
     float minT = maxDist;
     int hit = -1;
@@ -187,7 +189,8 @@ template <int COUNT>
 __device__ __forceinline__ bool trace_any(const SceneLds &sc, int nObj, const Ray &r, float maxDist,
                                            float limit, unsigned &rays) {
     if (COUNT) rays++;
-    v3 inv = V3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    v3 inv;
+    rtf::rcp3(r.d.x, r.d.y, r.d.z, inv.x, inv.y, inv.z);
     float a = dot(r.d, r.d);
     bool occ = false;
     for (int i = 0; i < nObj; i++) {
@@ -398,7 +401,7 @@ __device__ __forceinline__ v3 compute_lighting(const SceneLds &sc, const RtFrame
         if (ltype == 0) {
             lightDir = V3(l0) - P;
             lightDistance = length(lightDir);
-            attenuation = 1.0f / (1.0f + 0.1f * lightDistance + 0.01f * lightDistance * lightDistance);
+            attenuation = rtf::rcp(1.0f + 0.1f * lightDistance + 0.01f * lightDistance * lightDistance);
             lightDir = normalize(lightDir);
         } else if (ltype == 1) {
             lightDir = V3(l1);             // normalize(-direction), folded by the scene compiler
@@ -409,7 +412,7 @@ __device__ __forceinline__ v3 compute_lighting(const SceneLds &sc, const RtFrame
             float q = dot(lightDir, lightDir);
             lightDistance = length(lightDir);
             lightDir = normalize(lightDir);
-            attenuation = 1.0f / fabsf(q);
+            attenuation = rtf::rcp(fabsf(q));
             float lc = fmaxf(dot(lightDir, V3(l1)), 0.0f);   // l1 = normalize(direction)
             attenuation *= lc;
         }
@@ -439,7 +442,7 @@ __device__ __forceinline__ v3 compute_lighting(const SceneLds &sc, const RtFrame
 // calculateRefraction (:256-270)
 __device__ __forceinline__ v3 calc_refraction(const Ray &r, v3 N, float ior) {
     bool entering = dot(r.d, N) < 0.0f;
-    float eta = entering ? (1.0f / ior) : ior;
+    float eta = entering ? rtf::rcp(ior) : ior;
     v3 normal = entering ? N : -N;
     v3 rd = refract(normalize(r.d), normal, eta);
     if (dot(rd, rd) < 0.001f) rd = reflect(r.d, normal);
@@ -937,6 +940,14 @@ __global__ void rt_iota_kernel(unsigned *__restrict__ order, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) order[i] = (unsigned)i;
 }
+
+#if RT_FASTMATH_STATS
+extern "C" int rt_debug_fastmath_fallbacks(unsigned long long out[4], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtf::g_fallbacks), 32) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtf::g_fallbacks), z, 32) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
 
 hipError_t rt_launch_iota(unsigned *dOrder, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;

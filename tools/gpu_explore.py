@@ -21,7 +21,7 @@ for spec in specs:
     import re
     blocks = cr.stderr.split("Function Name: ")
     for b_ in blocks:
-        if b_.startswith("_Z23rt_render_packet_kernelILb0") or b_.startswith("_Z16rt_render_kernelILb0"):
+        if b_.startswith("_Z23rt_render_packet_kernelILi0") or b_.startswith("_Z16rt_render_kernelILi0"):
             g = lambda key: (re.search(key + r": (\d+)", b_) or [None, "?"])[1]
             vg, sc_, oc, sp = g("VGPRs"), g("ScratchSize .bytes.lane."), g("Occupancy .waves.SIMD."), g("SGPRs Spill")
             print(f"[{name}] {b_[:30]}: VGPR {vg} scratch {sc_} occ {oc} sgprspill {sp}", flush=True)

@@ -1,0 +1,59 @@
+"""Build macro variants of the library ON the GPU box and time them at the configs' full sizes in one gpurun call,
+checking every variant's three surfaces against the first variant's bit for bit.
+usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH]"""
+import os, re, subprocess, sys, zlib
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from opengl_raytracing_amd import build as B
+
+specs = [a for a in sys.argv[1:] if not a.startswith("--")]
+opt = {a.split("=")[0][2:]: a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
+cfgs, reps, size = opt.get("cfgs", "2"), int(opt.get("reps", "7")), opt.get("size")
+
+if os.environ.get("RT_TRY_CHILD"):
+    import numpy as np
+    from opengl_raytracing_amd import host, scenes
+    rt = host.RayTracer(0)
+    for cfg in [int(c) for c in cfgs.split(",")]:
+        sc = scenes.make_scene(cfg, host.generate_aabb)
+        w, h = (int(v) for v in size.split("x")) if size else (sc.width, sc.height)
+        p = sc.params(width=w, height=h)
+        rt.load(sc)
+        for _ in range(3):
+            rt.render(p); rt.sync()
+        ts = []
+        for _ in range(reps):
+            rt.render(p); rt.sync(); ts.append(rt.last_kernel_ms())
+        col, pos, nrm = rt.readback()
+        crc = zlib.crc32(nrm.tobytes(), zlib.crc32(pos.tobytes(), zlib.crc32(col.tobytes())))
+        rt.set_variant(0x101); rt.render(p); rt.sync(); rt.render(p); rt.sync(); cold = rt.last_kernel_ms(); rt.set_variant(1)
+        print(f"RESULT C{cfg} {w}x{h}: median {np.median(ts):.4f} ms  min {min(ts):.4f}  raster-order {cold:.4f}  crc {crc:08x}", flush=True)
+    sys.exit(0)
+
+os.makedirs("/tmp/rtx", exist_ok=True)
+ref = {}
+for spec in specs:
+    name, _, flags = spec.partition(":")
+    out = f"/tmp/rtx/lib_{name}.so"
+    srcs = [os.path.join(B.CSRC, s_) for s_ in B.SOURCES]
+    cmd = [B._hipcc(), *B.HIPCC_FLAGS, *flags.split(), "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(REPO, "include"),
+           "-I", B.CSRC, "-x", "hip", *srcs, "-o", out]
+    cr = subprocess.run(cmd, capture_output=True, text=True)
+    if cr.returncode:
+        print(f"[{name}] BUILD FAILED {cr.stderr[-600:]}", flush=True); continue
+    for b_ in cr.stderr.split("Function Name: "):
+        m = re.match(r"_Z23rt_render_packet_kernelILi0ELi(\d+)ELb(\d)E", b_)
+        if m:
+            g = lambda key: (re.search(key + r": (\d+)", b_) or [None, "?"])[1]
+            print(f"[{name}] kernel<0,{m.group(1)},{'compact' if m.group(2) == '1' else 'full'}>: VGPR {g('VGPRs')} scratch {g('ScratchSize .bytes.lane.')} "
+                  f"occ {g('Occupancy .waves.SIMD.')} sgpr-spill {g('SGPRs Spill')} vgpr-spill {g('VGPRs Spill')}", flush=True)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), *[a for a in sys.argv[1:] if a.startswith("--")]],
+                       env=dict(os.environ, RT_LIB=out, RT_TRY_CHILD="1"), capture_output=True, text=True)
+    for l in r.stdout.splitlines():
+        if l.startswith("RESULT"):
+            key = l.split(":")[0]
+            crc = l.rsplit("crc ", 1)[1]
+            ref.setdefault(key, crc)
+            print(f"[{name}] {l[7:]}  identical_to_first={crc == ref[key]}", flush=True)
+    if r.returncode:
+        print(f"[{name}] FAILED\n{r.stderr[-600:]}", flush=True)
