@@ -89,13 +89,14 @@ struct SceneLds {
     const float *halton3;  // RT_HALTON_N
     unsigned long long *stats = nullptr;   // diagnostic counters (instrumented build only)
     const float4 *global = nullptr;        // the same records in global memory (scalar-load path)
-    float *park = nullptr;                 // per-thread LDS parking area, 9 floats x BLOCK_THREADS (packet kernel)
+    float *park = nullptr;                 // per-thread LDS parking area, RT_PARK_FLOATS floats x BLOCK_THREADS (packet kernel)
     int tileX = 0, tileY = 0;              // this workgroup's tile (packet kernel; wave-uniform)
     int lgtF4Base = 0, haltonFloatBase = 0;   // offsets of the light / Halton sections (float4 / float units)
     // Compact staging (packet kernel, scenes too large to keep whole in LDS at full occupancy): LDS holds only
     // the two bounds float4 of every object (stride 2); shape / material records read per lane by hit index come
     // from the global copy.  hotStride = float4 stride of `hot`, matF4Base = material section in `global`.
     bool compact = false;
+    bool keepAabb = true;       // packet kernel profile: chunk 0's AABB lives in the lane's VGPRs (else re-read from LDS per cull pass)
     int hotStride = RT_HOT_F4, matF4Base = 0;
     int pcfTabF4 = -1;          // float4 index in `global` of the directional lights' PCF ray tables, -1 = not usable (noise bound)
 };
@@ -671,34 +672,32 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 // =========================================================================================
 // Render kernel, wavefront-packet variant (rt_packet.inc): same staging and lane->pixel map.
 // =========================================================================================
-// Instantiations: 64-thread workgroups (one wave, 8x8 tile: finer-grained scheduling, no intra-group imbalance)
-// for scenes of up to RT_PK_SMALL_SCENE objects -- the whole compiled scene in LDS up to RT_PK_SMALL_FULL objects
-// (108 VGPRs / 4 waves per SIMD, NO scratch), only the AABBs above that (COMPACT; PCF rays in pairs, 128 VGPRs) --
-// and 256-thread workgroups (16x16 tile, one AABB copy shared by four waves, 5 waves per SIMD = 96 VGPRs + 184 B/lane
-// of scratch) beyond.  Measured in DESIGN.md section 4 (C4: 4.0 -> 3.57 ms, C5: 12.7 -> 8.0 ms at 1080p against
-// four-wave workgroups with the whole scene in LDS).  Wave counts for the 256-thread shape, at full size
-// (C4 4K / C5 8K, before COMPACT): 6 waves (80 VGPRs, 240 B scratch) 12.0 / 108.1 ms, 5 waves 11.6 / 103.4,
-// 4 waves (128 VGPRs, 24 B) 12.5 / 101.2; the scratch shows up as HBM traffic.
-#ifndef RT_PK_WAVES_SMALL
-#define RT_PK_WAVES_SMALL 4
+// Instantiations.  One-wave workgroups (8x8 tile: the frame is a bag of independent wave-sized jobs, no intra-group
+// imbalance) for scenes of up to RT_PK_SMALL_SCENE objects; LDS holds only the two bounds float4 of every object
+// (COMPACT staging: wave-uniform records come by scalar loads, the hit object's shape / material fields by per-lane loads
+// from the global copy) plus the per-lane parking area.  Two profiles (rt_packet.inc): LIGHT up to RT_PK_LIGHT_SCENE
+// objects -- 5 waves/SIMD at 96 VGPRs, no scratch -- and HEAVY above -- 4 waves/SIMD at 128 VGPRs, PCF rays in pairs.
+// Beyond RT_PK_SMALL_SCENE objects sixteen waves' AABB copies no longer fit a CU: 256-thread workgroups (16x16 tile, one
+// AABB copy shared by four waves, HEAVY profile at 5 waves/SIMD).  Measured, C2 / C3 / C4 / C5 in ms at full size
+// (gpurun_out/try8..14.log): round-1 shapes (whole scene in LDS, 4 waves) 0.459 / 5.27 / 8.25 / 48.4;
+// LIGHT 0.407 / 4.86 / 9.65 / 76 (LDS-capped on the large scenes); HEAVY 0.462 / 5.54 / 8.25 / 48.4.
+#ifndef RT_PK_WAVES_LIGHT
+#define RT_PK_WAVES_LIGHT 5
 #endif
-#ifndef RT_PK_WAVES_SMALL_COMPACT
-#define RT_PK_WAVES_SMALL_COMPACT 4
+#ifndef RT_PK_WAVES_HEAVY
+#define RT_PK_WAVES_HEAVY 4
 #endif
 #ifndef RT_PK_WAVES_LARGE
 #define RT_PK_WAVES_LARGE 5
 #endif
 #ifndef RT_PK_SMALL_SCENE
-#define RT_PK_SMALL_SCENE 256   // objects: at or below, one-wave workgroups (16 waves x (32 B/object + parking) fit a CU's LDS)
+#define RT_PK_SMALL_SCENE 256   // objects: at or below, one-wave workgroups
 #endif
-#ifndef RT_PK_SMALL_FULL
-#define RT_PK_SMALL_FULL 32     // objects: one-wave workgroups stage the whole scene up to here, only the AABBs above
+#ifndef RT_PK_LIGHT_SCENE
+#define RT_PK_LIGHT_SCENE 32    // objects: at or below, the LIGHT profile
 #endif
-#ifndef RT_PK_COMPACT_SCENE
-#define RT_PK_COMPACT_SCENE 144  // objects: above (5 workgroups x (160 B/object + parking) no longer fit a CU), stage only the AABBs in LDS
-#endif
-template <int COUNT, int BT, bool COMPACT>
-__global__ __launch_bounds__(BT, (BT == 64 ? (COMPACT ? RT_PK_WAVES_SMALL_COMPACT : RT_PK_WAVES_SMALL) : RT_PK_WAVES_LARGE))
+template <int COUNT, int BT, bool COMPACT, typename PROFILE>
+__global__ __launch_bounds__(BT, (BT == 64 ? (PROFILE::park2 ? RT_PK_WAVES_LIGHT : RT_PK_WAVES_HEAVY) : RT_PK_WAVES_LARGE))
 void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
                              float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
                              unsigned long long *rayCounter) {
@@ -713,6 +712,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     __syncthreads();
     SceneLds sc;
     sc.compact = COMPACT;
+    sc.keepAabb = PROFILE::keepAabb;
     sc.hotStride = COMPACT ? 2 : RT_HOT_F4;
     sc.matF4Base = f.nObj * RT_HOT_F4;
     sc.hot = lds;
@@ -739,7 +739,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     const long long t0 = clock64();
 
     unsigned rays = 0;
-    render_packet<COUNT, BT, (BT == 256 ? RT_PK_GROUP_LARGE : (COMPACT ? RT_PK_GROUP_SMALL_COMPACT : RT_PK_GROUP_SMALL))>(f, dsc, sc, gColor, gPosition, gNormal, rays);
+    render_packet<COUNT, BT, PROFILE>(f, dsc, sc, gColor, gPosition, gNormal, rays);
 
     if (dsc.tileCost && (threadIdx.x & 63) == 0) {     // one add per wave: tile cost = sum of its waves' cycles / 64
         const unsigned c = (unsigned)(((unsigned long long)(clock64() - t0)) >> 6);
@@ -853,32 +853,25 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
                             uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s, int countMode) {
     if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
-    const size_t sceneBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // +16 B: COUNT build's block counter
+    const size_t sceneBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // exhaustive kernel: whole scene + 16 B block counter
     if (variant == 1) {
         int bt, tile, tilesX, nTiles;
         rt_packet_geometry(f.nObj, f.p.regionW, f.p.regionH, &bt, &tile, &tilesX, &nTiles);
-        const bool small = bt == 64;
         dim3 grid(nTiles);
-        const size_t ldsBytes = sceneBytes + 9 * bt * sizeof(float);                    // + the parking area
-        if (small && f.nObj > RT_PK_SMALL_FULL) {      // one-wave workgroups, AABBs only in LDS
-            const size_t compactBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) + 9 * bt * sizeof(float);
-            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 64, true>), grid, dim3(64), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-        } else if (small) {
-            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 64, false>), grid, dim3(64), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-        } else if (f.nObj > RT_PK_COMPACT_SCENE) {
-            const size_t compactBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) + 9 * bt * sizeof(float);
-            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 256, true>), grid, dim3(256), compactBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-        } else {
-            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-            else hipLaunchKernelGGL((rt_render_packet_kernel<0, 256, false>), grid, dim3(256), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
-        }
+        const bool light = bt == 64 && f.nObj <= RT_PK_LIGHT_SCENE;
+        // LDS: the AABBs (2 float4 per object) + the 16-byte counter slot + the profile's parking area
+        const size_t ldsBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) +
+                                (size_t)(light ? PkLight::parkFloats : PkHeavy::parkFloats) * bt * sizeof(float);
+#define RT_LAUNCH_PK(BT_, PROFILE_)                                                                                                   \
+        do {                                                                                                                          \
+            if (dRayCounter && countMode == 2) hipLaunchKernelGGL((rt_render_packet_kernel<2, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter); \
+            else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);            \
+            else hipLaunchKernelGGL((rt_render_packet_kernel<0, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);                             \
+        } while (0)
+        if (light) RT_LAUNCH_PK(64, PkLight);
+        else if (bt == 64) RT_LAUNCH_PK(64, PkHeavy);
+        else RT_LAUNCH_PK(256, PkHeavy);
+#undef RT_LAUNCH_PK
     } else {
         dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
         if (dRayCounter)

@@ -21,9 +21,14 @@ if os.environ.get("RT_TRY_CHILD"):
         rt.load(sc)
         for _ in range(3):
             rt.render(p); rt.sync()
+        import time
         ts = []
-        for _ in range(reps):
-            rt.render(p); rt.sync(); ts.append(rt.last_kernel_ms())
+        k = 40 if w * h <= 1920 * 1080 else (12 if w * h <= 3840 * 2160 else 5)
+        for _ in range(reps):          # like bench.py: k back-to-back launches, wall clock around the batch
+            rt.sync(); t0 = time.perf_counter()
+            for _ in range(k):
+                rt.render(p)
+            rt.sync(); ts.append((time.perf_counter() - t0) / k * 1e3)
         col, pos, nrm = rt.readback()
         crc = zlib.crc32(nrm.tobytes(), zlib.crc32(pos.tobytes(), zlib.crc32(col.tobytes())))
         rt.set_variant(0x101); rt.render(p); rt.sync(); rt.render(p); rt.sync(); cold = rt.last_kernel_ms(); rt.set_variant(1)
@@ -42,10 +47,10 @@ for spec in specs:
     if cr.returncode:
         print(f"[{name}] BUILD FAILED {cr.stderr[-600:]}", flush=True); continue
     for b_ in cr.stderr.split("Function Name: "):
-        m = re.match(r"_Z23rt_render_packet_kernelILi0ELi(\d+)ELb(\d)E", b_)
+        m = re.match(r"_Z23rt_render_packet_kernelILi0ELi(\d+)ELb(\d)E(\S*?)(Pk\w+?)E", b_)
         if m:
             g = lambda key: (re.search(key + r": (\d+)", b_) or [None, "?"])[1]
-            print(f"[{name}] kernel<0,{m.group(1)},{'compact' if m.group(2) == '1' else 'full'}>: VGPR {g('VGPRs')} scratch {g('ScratchSize .bytes.lane.')} "
+            print(f"[{name}] kernel<0,{m.group(1)},{m.group(4)}>: VGPR {g('VGPRs')} scratch {g('ScratchSize .bytes.lane.')} "
                   f"occ {g('Occupancy .waves.SIMD.')} sgpr-spill {g('SGPRs Spill')} vgpr-spill {g('VGPRs Spill')}", flush=True)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), *[a for a in sys.argv[1:] if a.startswith("--")]],
                        env=dict(os.environ, RT_LIB=out, RT_TRY_CHILD="1"), capture_output=True, text=True)
