@@ -25,7 +25,7 @@ extern "C" {
 
 #define RT_OBJECT_STRIDE 176 /* sizeof(Object), /root/reference/src/Object.h:13-21 */
 #define RT_LIGHT_STRIDE 96   /* sizeof(Light),  /root/reference/src/Light.h:7-20  */
-#define RT_MAX_OBJECTS 512   /* LDS budget: 512 * (96 + 64) B = 80 KiB of the CU's 160 KiB */
+#define RT_MAX_OBJECTS 512   /* the exhaustive kernel (variant 0) stages the whole scene: 512 * 160 B = 80 KiB of the CU's 160 KiB LDS */
 #define RT_MAX_LIGHTS 64
 
 typedef enum rt_status {
@@ -187,6 +187,11 @@ int rt_set_variant(rt_context *ctx, int variant);
  * out[2] candidate objects summed over packets (after packet culling), out[3] 64-object cull
  * passes.  [1..3] are zero for variant 0 (no packet culling). */
 int rt_debug_stats(rt_context *ctx, uint64_t out[4]);
+/* The same plus packet-coherence diagnostics of the packet kernel: out[4..7] packets whose direction boxes leave 3 / 2 / 1 / 0
+ * axes usable for culling (an axis is lost when the packet's directions straddle zero on it), out[8] packets that cannot be
+ * culled at all (NaN lanes, non-finite origins), out[9] / out[10] candidates summed over the 3-axis packets / the others,
+ * out[11] active lanes summed over packets. */
+int rt_debug_stats_ex(rt_context *ctx, uint64_t out[16]);
 /* Measured cost (shader clock cycles / 64, summed over the tile's waves) of every workgroup tile of the
  * last feedback-scheduled rt_render / rt_render_to launch, in raster tile order; synchronises.  Writes up
  * to cap entries, *nTiles / *tilesX describe the tile grid.  Measurement hook, no reference counterpart. */

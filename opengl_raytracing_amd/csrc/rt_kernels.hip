@@ -96,6 +96,8 @@ struct SceneLds {
     // the two bounds float4 of every object (stride 2); shape / material records read per lane by hit index come
     // from the global copy.  hotStride = float4 stride of `hot`, matF4Base = material section in `global`.
     bool compact = false;
+    bool boundsLds = true;      // packet kernel profile: the cull passes' per-lane AABB reads come from LDS (else from the global copy)
+    bool split = false;         // packet kernel profile: octant-split culling of sign-straddling packets
     bool keepAabb = true;       // packet kernel profile: chunk 0's AABB lives in the lane's VGPRs (else re-read from LDS per cull pass)
     int hotStride = RT_HOT_F4, matF4Base = 0;
     int pcfTabF4 = -1;          // float4 index in `global` of the directional lights' PCF ray tables, -1 = not usable (noise bound)
@@ -673,37 +675,27 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 // Render kernel, wavefront-packet variant (rt_packet.inc): same staging and lane->pixel map.
 // =========================================================================================
 // Instantiations.  One-wave workgroups (8x8 tile: the frame is a bag of independent wave-sized jobs, no intra-group
-// imbalance) for scenes of up to RT_PK_SMALL_SCENE objects; LDS holds only the two bounds float4 of every object
-// (COMPACT staging: wave-uniform records come by scalar loads, the hit object's shape / material fields by per-lane loads
-// from the global copy) plus the per-lane parking area.  Two profiles (rt_packet.inc): LIGHT up to RT_PK_LIGHT_SCENE
-// objects -- 5 waves/SIMD at 96 VGPRs, no scratch -- and HEAVY above -- 4 waves/SIMD at 128 VGPRs, PCF rays in pairs.
-// Beyond RT_PK_SMALL_SCENE objects sixteen waves' AABB copies no longer fit a CU: 256-thread workgroups (16x16 tile, one
-// AABB copy shared by four waves, HEAVY profile at 5 waves/SIMD).  Measured, C2 / C3 / C4 / C5 in ms at full size
-// (gpurun_out/try8..14.log): round-1 shapes (whole scene in LDS, 4 waves) 0.459 / 5.27 / 8.25 / 48.4;
-// LIGHT 0.407 / 4.86 / 9.65 / 76 (LDS-capped on the large scenes); HEAVY 0.462 / 5.54 / 8.25 / 48.4.
-#ifndef RT_PK_WAVES_LIGHT
-#define RT_PK_WAVES_LIGHT 5
-#endif
-#ifndef RT_PK_WAVES_HEAVY
-#define RT_PK_WAVES_HEAVY 4
-#endif
-#ifndef RT_PK_WAVES_LARGE
-#define RT_PK_WAVES_LARGE 5
-#endif
-#ifndef RT_PK_SMALL_SCENE
-#define RT_PK_SMALL_SCENE 256   // objects: at or below, one-wave workgroups
+// imbalance) for every scene the ABI accepts (<= RT_MAX_OBJECTS).  Wave-uniform records (the candidate being tested, the
+// current light, Halton entries) come by scalar loads from the global copy of the compiled scene, the hit object's shape /
+// material fields by per-lane loads from it; LDS holds the per-lane parking area and, in the LIGHT profile, the AABBs.
+// Profiles: rt_packet.inc.  Measured on one MI355X, ms/frame at full size (gpurun_out/try8..19.log):
+//                                                     C2       C3      C4      C5
+//   round 1 shapes (whole scene in LDS, 4 waves/SIMD)  0.459    5.27    8.25    48.4   (after the fast 1/x, sqrt paths)
+//   LIGHT / HEAVY profiles                             0.404    4.84    8.15    43.2
+#ifndef RT_PK_WAVES_SMALL
+#define RT_PK_WAVES_SMALL 5
 #endif
 #ifndef RT_PK_LIGHT_SCENE
 #define RT_PK_LIGHT_SCENE 32    // objects: at or below, the LIGHT profile
 #endif
 template <int COUNT, int BT, bool COMPACT, typename PROFILE>
-__global__ __launch_bounds__(BT, (BT == 64 ? (PROFILE::park2 ? RT_PK_WAVES_LIGHT : RT_PK_WAVES_HEAVY) : RT_PK_WAVES_LARGE))
+__global__ __launch_bounds__(BT, RT_PK_WAVES_SMALL)
 void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
                              float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
                              unsigned long long *rayCounter) {
     extern __shared__ float4 lds[];
     const int nAll = f.nObj * (RT_HOT_F4 + RT_MAT_F4) + f.nLt * RT_LGT_F4 + 2 * (RT_HALTON_N / 4);
-    const int nF4 = COMPACT ? f.nObj * 2 : nAll;          // float4 staged in LDS
+    const int nF4 = !PROFILE::boundsLds ? 0 : (COMPACT ? f.nObj * 2 : nAll);          // float4 staged in LDS
     if (COMPACT) {
         for (int i = threadIdx.x; i < nF4; i += BT) lds[i] = dsc.compiled[(i >> 1) * RT_HOT_F4 + (i & 1)];
     } else {
@@ -713,6 +705,8 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     SceneLds sc;
     sc.compact = COMPACT;
     sc.keepAabb = PROFILE::keepAabb;
+    sc.boundsLds = PROFILE::boundsLds;
+    sc.split = PROFILE::split;
     sc.hotStride = COMPACT ? 2 : RT_HOT_F4;
     sc.matF4Base = f.nObj * RT_HOT_F4;
     sc.hot = lds;
@@ -860,7 +854,7 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
         dim3 grid(nTiles);
         const bool light = bt == 64 && f.nObj <= RT_PK_LIGHT_SCENE;
         // LDS: the AABBs (2 float4 per object) + the 16-byte counter slot + the profile's parking area
-        const size_t ldsBytes = ((size_t)f.nObj * 2 + 1) * sizeof(float4) +
+        const size_t ldsBytes = ((size_t)((light || PkHeavy::boundsLds) ? f.nObj * 2 : 0) + 1) * sizeof(float4) +
                                 (size_t)(light ? PkLight::parkFloats : PkHeavy::parkFloats) * bt * sizeof(float);
 #define RT_LAUNCH_PK(BT_, PROFILE_)                                                                                                   \
         do {                                                                                                                          \
@@ -869,8 +863,7 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
             else hipLaunchKernelGGL((rt_render_packet_kernel<0, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);                             \
         } while (0)
         if (light) RT_LAUNCH_PK(64, PkLight);
-        else if (bt == 64) RT_LAUNCH_PK(64, PkHeavy);
-        else RT_LAUNCH_PK(256, PkHeavy);
+        else RT_LAUNCH_PK(64, PkHeavy);
 #undef RT_LAUNCH_PK
     } else {
         dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
@@ -883,9 +876,9 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
 }
 
 void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles) {
-    const bool small = nObj <= RT_PK_SMALL_SCENE;
-    *bt = small ? 64 : 256;
-    *tile = small ? 8 : 16;
+    (void)nObj;         // one-wave workgroups / 8x8-pixel tiles for every scene size (the 256-thread shape is retired)
+    *bt = 64;
+    *tile = 8;
     *tilesX = (regionW + *tile - 1) / *tile;
     *nTiles = *tilesX * ((regionH + *tile - 1) / *tile);
 }

@@ -127,13 +127,10 @@ class StripPlan:
 
 
 def default_strip_rows(height, world, n_objects=None):
-    """One workgroup tile per strip: 8 rows when the scene runs the one-wave 8x8-tile kernel
-    (<= 256 objects), 16 otherwise.  Short strips keep every rank's share of the benchmark scenes
-    within a few percent of equal and the padding of the equal-sized gather buffers small
-    (1080p on 8 GPUs: 8-row strips pad 1080 -> 1088 rows, 16-row strips -> 1152)."""
-    if n_objects is not None and n_objects <= 256:
-        return 8
-    return 16
+    """One workgroup tile per strip: the packet kernel renders 8x8-pixel tiles for every scene size.  Short
+    strips keep every rank's share of the benchmark scenes within a few percent of equal and the padding of
+    the equal-sized gather buffers small (1080p on 8 GPUs: 8-row strips pad 1080 -> 1088 rows)."""
+    return 8
 
 
 def alloc_rank_buffer(plan, device, rank=None):

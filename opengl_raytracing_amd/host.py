@@ -31,7 +31,7 @@ _LIB = None
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_noise", "rt_set_skybox", "rt_render",
     "rt_render_to", "rt_sync", "rt_readback", "rt_get_surfaces", "rt_last_kernel_ms",
-    "rt_count_rays", "rt_count_rays_traced", "rt_debug_stats", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
+    "rt_count_rays", "rt_count_rays_traced", "rt_debug_stats", "rt_debug_stats_ex", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
     "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_frame", "rt_frame_surfaces", "rt_strip_local_rows", "rt_deinterleave",
     "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack", "rt_debug_mesa_math",
@@ -86,6 +86,7 @@ def load_library(build_if_missing=True):
     lib.rt_count_rays_traced.argtypes = [vp, P(L.RtParams), P(ctypes.c_uint64)]
     lib.rt_set_variant.argtypes = [vp, ci]
     lib.rt_debug_stats.argtypes = [vp, P(ctypes.c_uint64)]
+    lib.rt_debug_stats_ex.argtypes = [vp, P(ctypes.c_uint64)]
     lib.rt_debug_tile_costs.argtypes = [vp, P(ctypes.c_uint32), ci, P(ci), P(ci)]
     lib.rt_last_error.argtypes = [vp]
     lib.rt_last_error.restype = ctypes.c_char_p
@@ -411,6 +412,11 @@ class RayTracer:
     def debug_stats(self):
         out = (ctypes.c_uint64 * 4)()
         self._check(self.lib.rt_debug_stats(self.ctx, out), "rt_debug_stats")
+        return list(out)
+
+    def debug_stats_ex(self):
+        out = (ctypes.c_uint64 * 16)()
+        self._check(self.lib.rt_debug_stats_ex(self.ctx, out), "rt_debug_stats_ex")
         return list(out)
 
     def deinterleave(self, d_src, d_dst, width, height, bytes_per_pixel, strip_rows, strip_count,
