@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 and -3 `gloo` process groups run the same strip plan,
+"""N > 1 path on CPU: world_size-2, -3, -4 and -8 `gloo` process groups run the same strip plan,
 gather and re-assembly code the GPU bench uses (opengl_raytracing_amd/dist.py).  The strips
 are rendered by the oracle here (tests may use it; there is no GPU in this container) -- what
 is under test is the partition + gather + de-interleave logic, which must reproduce the
@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, strip_rows, w, h, out_path, root_weight):
+def _worker(rank, world, port, strip_rows, w, h, out_path, root_weight, cfg=2):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, strip_rows, w, h, out_path, root_weight):
     from opengl_raytracing_amd import host, scenes
     from oracle import binding as O
 
-    sc = scenes.make_scene(2, host.generate_aabb)
+    sc = scenes.make_scene(cfg, host.generate_aabb)
     base = sc.params(width=w, height=h)
     plan = D.StripPlan(w, h, strip_rows, world, root_weight)
     p = plan.params(base, rank)
@@ -71,16 +71,20 @@ def _worker(rank, world, port, strip_rows, w, h, out_path, root_weight):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,strip_rows,size,root_weight", [(2, 16, (96, 70), 1), (3, 8, (64, 45), 1), (2, 8, (64, 70), 2),
-                                                               (3, 8, (48, 61), 3)])
-def test_gloo_strip_gather_reproduces_single_frame(tmp_path, world, strip_rows, size, root_weight):
+# (world, strip rows, size, root weight, config): worlds 2 / 3 on the benchmark scene, and worlds 4 / 8 with the plan shape
+# bench.py uses for the 8K frame the tiling was designed for -- C5's scene (256 objects, depth 8, skybox), 8-row strips,
+# equal and weighted roots, image heights that leave the last cycle ragged (some ranks own no rows of it)
+@pytest.mark.parametrize("world,strip_rows,size,root_weight,cfg", [(2, 16, (96, 70), 1, 2), (3, 8, (64, 45), 1, 2), (2, 8, (64, 70), 2, 2),
+                                                                   (3, 8, (48, 61), 3, 2), (4, 8, (40, 75), 2, 5), (8, 8, (32, 100), 1, 5),
+                                                                   (8, 8, (24, 150), 3, 5)])
+def test_gloo_strip_gather_reproduces_single_frame(tmp_path, world, strip_rows, size, root_weight, cfg):
     from opengl_raytracing_amd import host, scenes
     from oracle import binding as O
     w, h = size
     out = str(tmp_path / "full.npz")
-    mp.spawn(_worker, args=(world, _free_port(), strip_rows, w, h, out, root_weight), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), strip_rows, w, h, out, root_weight, cfg), nprocs=world, join=True)
     got = np.load(out)
-    sc = scenes.make_scene(2, host.generate_aabb)
+    sc = scenes.make_scene(cfg, host.generate_aabb)
     col, pos, nrm, rays = O.render(sc, sc.params(width=w, height=h))
     assert np.array_equal(got["color"], col, equal_nan=True)
     assert np.array_equal(got["pos"], pos, equal_nan=True)
