@@ -97,6 +97,7 @@ struct SceneLds {
     // from the global copy.  hotStride = float4 stride of `hot`, matF4Base = material section in `global`.
     bool compact = false;
     bool boundsLds = true;      // packet kernel profile: the cull passes' per-lane AABB reads come from LDS (else from the global copy)
+    bool wedge = false;         // packet kernel profile: convergent-packet cull of point / area light shadow rays
     bool split = false;         // packet kernel profile: octant-split culling of sign-straddling packets
     bool keepAabb = true;       // packet kernel profile: chunk 0's AABB lives in the lane's VGPRs (else re-read from LDS per cull pass)
     int hotStride = RT_HOT_F4, matF4Base = 0;
@@ -707,6 +708,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     sc.keepAabb = PROFILE::keepAabb;
     sc.boundsLds = PROFILE::boundsLds;
     sc.split = PROFILE::split;
+    sc.wedge = PROFILE::wedge;
     sc.hotStride = COMPACT ? 2 : RT_HOT_F4;
     sc.matF4Base = f.nObj * RT_HOT_F4;
     sc.hot = lds;
@@ -863,6 +865,7 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
             else hipLaunchKernelGGL((rt_render_packet_kernel<0, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);                             \
         } while (0)
         if (light) RT_LAUNCH_PK(64, PkLight);
+        else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1);
         else RT_LAUNCH_PK(64, PkHeavy);
 #undef RT_LAUNCH_PK
     } else {
