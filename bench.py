@@ -246,6 +246,10 @@ def main():
     ap.add_argument("--extra-configs", default="3,4,5",
                     help="further configs measured after the headline and reported under `configs_extra` "
                          "(N = 1: comma list, default 3,4,5; N > 1: default 5 = the 8K frame the tiling was designed for); 'none' skips")
+    ap.add_argument("--no-modes", action="store_true",
+                    help="N = 1: skip the free-running-frameCount and raster-order (cold) measurements, so that every launch of the "
+                         "dominant kernel in the process belongs to the headline loop (profiles/run_profile.sh uses this: "
+                         "rocprofv3's per-kernel average is then the headline kernel_ms)")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=1, help="1 = packet kernel (default), 0 = exhaustive loop")
@@ -280,7 +284,7 @@ def main():
 
     # ------------------------------------------------------------------------------------------------ N = 1
     if world == 1 and (args.frames_in_flight or 0) <= 1:
-        r = measure_single(args.config, args.steps, args.warmup, args.variant, local_rank)
+        r = measure_single(args.config, args.steps, args.warmup, args.variant, local_rank, with_modes=not args.no_modes)
         rec = single_record(args.config, r, args.steps, args.warmup, src_hash)
         sc = r["sc"]
         out = {"metric": "Mray/s", "value": rec["value_mray_s"], "unit": "Mray/s", "n_gpus": 1, "steps": args.steps,

@@ -8,7 +8,7 @@ set -o pipefail
 #   RT_PROFILE_PROG=tools/bench_bloom.py (or tools/bench_taa.py) profiles a secondary chain instead of bench.py.
 TAG=${1:-r01}; shift
 PROG=${RT_PROFILE_PROG:-bench.py}
-if [ "$PROG" = bench.py ]; then ARGS=${@:---steps 30 --warmup 5 --no-cpu-baseline}; else ARGS=$@; fi
+if [ "$PROG" = bench.py ]; then ARGS=${@:---steps 30 --warmup 5 --no-cpu-baseline --extra-configs none --no-modes}; else ARGS=$@; fi
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT

@@ -11,8 +11,15 @@ from collections import defaultdict
 
 
 def main(src, prefix):
+    def newest(pattern):
+        """gpurun MERGES output directories: keep only the most recent file of each rocprofv3 output directory."""
+        by_dir = defaultdict(list)
+        for f in glob.glob(pattern, recursive=True):
+            by_dir[os.path.dirname(f)].append(f)
+        return [max(fs, key=os.path.getmtime) for fs in by_dir.values()]
+
     stats = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
-    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in newest(os.path.join(src, "trace", "**", "*kernel_trace.csv")):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "?")
             dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
@@ -27,7 +34,7 @@ def main(src, prefix):
             meta = stats.get(name + "|meta", [""] * 5)
             out.write(f"\"{name}\",{s[0]},{s[1] / s[0]:.3f},{s[2]:.3f},{s[3]:.3f},{s[1]:.1f},{','.join(str(m) for m in meta)}\n")
     pmc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             pmc[row.get("Kernel_Name", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
     res = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in pmc.items()}
