@@ -59,7 +59,7 @@ def main(src, prefix):
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
             rec = {c: v["mean"] for c, v in cs.items()}
             rec.update({"fetch_size_kb": cs.get("FETCH_SIZE", {}).get("mean"), "write_size_kb": cs.get("WRITE_SIZE", {}).get("mean"),
-                        "kernel": k.split("(")[0], "source": os.path.basename(prefix) + "_pmc.json", "src_hash": src_hash})
+                        "kernel": (k[:k.index(">(") + 1] if ">(" in k else k.split("(")[0]), "source": os.path.basename(prefix) + "_pmc.json", "src_hash": src_hash})
             st = stats.get(k)
             if st:
                 rec["kernel_avg_us"] = round(st[1] / st[0], 3)
