@@ -251,6 +251,9 @@ __device__ __forceinline__ void blur_window2(const rt_f2 (&r)[N + 8], const rt_f
     orr = ar; og = ag; ob = ab;
 }
 
+#ifndef RT_BLOOM_TPW
+#define RT_BLOOM_TPW 1      // tiles per workgroup of the fused kernels (see rt_bloom_hv_kernel)
+#endif
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(256) void rt_bloom_hv_kernel(const void *__restrict__ inV, const float4 *__restrict__ scene,
                                                           void *__restrict__ outV, int W, int H, float threshold, float strength) {
@@ -259,22 +262,48 @@ __global__ __launch_bounds__(256) void rt_bloom_hv_kernel(const void *__restrict
     // patch rows 0..IH-1, tile columns 0..FX-1.  18.7 KB per workgroup: 8 workgroups (32 waves) per CU.
     __shared__ uint2 sin_[IH * IWP];
     uint2 *sh_ = sin_;
-    const int x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
-    // ---- stage the input patch (coalesced along rows)
-    for (int k = threadIdx.x; k < IW * IH; k += 256) {
-        const int lx = k % IW, ly = k / IW;
-        const int gx = min(max(x0 + lx - AP, 0), W - 1), gy = min(max(y0 + ly - AP, 0), H - 1);
+    // The patch is REQUESTED as one batch of NLD independent loads per thread into registers and written to LDS afterwards
+    // (round 1 interleaved load -> ds_write per texel, which serialised the memory latency: 88 -> 72 us for the 1080p chain,
+    // 249 -> 226 us at 4K).  The tile loop also lets a workgroup walk several tiles with the next patch in flight during
+    // the two passes (RT_BLOOM_TPW tiles per workgroup): measured SLOWER -- 72 / 79 / 81 / 96 / 104 us at 1, 2, 3, 4, 6
+    // tiles per workgroup at 1080p -- the 1 350 one-tile workgroups are all co-resident and cover each other's phases
+    // better than fewer, longer-lived ones; the default stays one tile per workgroup.
+    const int tilesX = (W + FX - 1) / FX, nTiles = tilesX * ((H + FY - 1) / FY);
+    constexpr int NLD = (IW * IH) / 256;                               // patch texels per thread (9)
+    static_assert(NLD * 256 == IW * IH, "whole patch in NLD loads per thread");
+    float4 preF[FIRST ? NLD : 1];                                      // FIRST: the rgba32f scene texel (extract happens at the LDS write)
+    uint2 preH[FIRST ? 1 : NLD];
+    auto request = [&](int tile) {
+        const int x0 = (tile % tilesX) * FX, y0 = (tile / tilesX) * FY;
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int k = threadIdx.x + j * 256;
+            const int lx = k % IW, ly = k / IW;
+            const int gx = min(max(x0 + lx - AP, 0), W - 1), gy = min(max(y0 + ly - AP, 0), H - 1);
+            if (FIRST) preF[j] = scene[(size_t)gy * W + gx];
+            else preH[j] = ((const uint2 *)inV)[(size_t)gy * W + gx];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < nTiles) request(tile);
+    for (; tile < nTiles; tile += (RT_BLOOM_TPW == 1 ? nTiles : (int)gridDim.x)) {      // (one trip when RT_BLOOM_TPW == 1)
+    const int x0 = (tile % tilesX) * FX, y0 = (tile / tilesX) * FY;
+    // ---- the requested patch -> LDS
+#pragma unroll
+    for (int j = 0; j < NLD; j++) {
+        const int k = threadIdx.x + j * 256;
         uint2 v;
         if (FIRST) {     // brightness_extractFS.glsl:11-19 on the fly
-            const float4 c = scene[(size_t)gy * W + gx];
+            const float4 c = preF[j];
             const float brightness = (c.z * 0.0722f + c.y * 0.7152f) + c.x * 0.2126f;
             v = (brightness > threshold) ? pack_half4(c.x, c.y, c.z) : make_uint2(0u, 0x3c00u << 16);
         } else {
-            v = ((const uint2 *)inV)[(size_t)gy * W + gx];
+            v = preH[j];
         }
-        sin_[ly * IWP + lx] = v;
+        sin_[(k / IW) * IWP + (k % IW)] = v;
     }
     __syncthreads();
+    if (RT_BLOOM_TPW > 1 && tile + (int)gridDim.x < nTiles) request(tile + (int)gridDim.x);     // in flight during the two passes below
     {   // ---- horizontal pass: lane -> patch rows (rp, rp+16), 4 consecutive columns of each
         const int rp = threadIdx.x % (IH / 2), grp = threadIdx.x / (IH / 2);
         rt_f2 r[HSPAN + 8], g[HSPAN + 8], b[HSPAN + 8];
@@ -303,6 +332,7 @@ __global__ __launch_bounds__(256) void rt_bloom_hv_kernel(const void *__restrict
             r[c].x = h2f_u(v0.x); g[c].x = h2f_u(v0.x >> 16); b[c].x = h2f_u(v0.y);
             r[c].y = h2f_u(v1.x); g[c].y = h2f_u(v1.x >> 16); b[c].y = h2f_u(v1.y);
         }
+        __syncthreads();     // the horizontal result is in registers: the next tile's patch may overwrite the LDS array
 #pragma unroll
         for (int k = 0; k < VSPAN; k++) {
             const int y = y0 + seg * VSPAN + k;
@@ -324,6 +354,7 @@ __global__ __launch_bounds__(256) void rt_bloom_hv_kernel(const void *__restrict
             }
         }
     }
+    }   // tiles of this workgroup
 }
 
 hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out, int W, int H, float threshold, float strength,
@@ -335,7 +366,8 @@ hipError_t rt_launch_bloom(const void *scene, void *tmpA, void *tmpB, void *out,
     const float4 *sc = (const float4 *)scene;
     const int pairs = iterations / 2;
     const bool odd = (iterations & 1) != 0;
-    dim3 fgrid((W + FX - 1) / FX, (H + FY - 1) / FY), grid((W + 63) / 64, (H + 3) / 4);
+    const int nTilesF = ((W + FX - 1) / FX) * ((H + FY - 1) / FY);
+    dim3 fgrid((nTilesF + RT_BLOOM_TPW - 1) / RT_BLOOM_TPW), grid((W + 63) / 64, (H + 3) / 4);
     if (pairs == 0) {            // 0 or 1 iterations: the unfused kernels
         hipLaunchKernelGGL(rt_bloom_extract_kernel, dim3(blocks), dim3(256), 0, s, sc, a, n, threshold);
         if (odd) { hipLaunchKernelGGL(rt_bloom_blur_kernel<true>, grid, dim3(256), 0, s, a, b, W, H); a = b; }
