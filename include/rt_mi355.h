@@ -190,8 +190,10 @@ int rt_debug_stats(rt_context *ctx, uint64_t out[4]);
 /* The same plus packet-coherence diagnostics of the packet kernel: out[4..7] packets whose direction boxes leave 3 / 2 / 1 / 0
  * axes usable for culling (an axis is lost when the packet's directions straddle zero on it), out[8] packets that cannot be
  * culled at all (NaN lanes, non-finite origins), out[9] / out[10] candidates summed over the 3-axis packets / the others,
- * out[11] active lanes summed over packets. */
-int rt_debug_stats_ex(rt_context *ctx, uint64_t out[16]);
+ * out[11] active lanes summed over packets; out[12..19] section timers of a -DRT_PK_TIMERS=1 build (shader clocks summed over
+ * waves; zero otherwise): closest-hit traversals, a light's packet + candidate masks, its PCF sample loops, the whole wave,
+ * the light packet's set-up alone, masks of octant-split light packets, split / unsplit light packets.  out[20..31] reserved. */
+int rt_debug_stats_ex(rt_context *ctx, uint64_t out[32]);
 /* Measured cost (shader clock cycles / 64, summed over the tile's waves) of every workgroup tile of the
  * last feedback-scheduled rt_render / rt_render_to launch, in raster tile order; synchronises.  Writes up
  * to cap entries, *nTiles / *tilesX describe the tile grid.  Measurement hook, no reference counterpart. */

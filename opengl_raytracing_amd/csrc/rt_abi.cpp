@@ -42,7 +42,7 @@ struct rt_context {
     int surfW = 0, surfH = 0;
     unsigned long long *dRayCounter = nullptr;
     int variant = 1;   // 1 = wavefront-packet kernel (default), 0 = exhaustive per-lane loop
-    unsigned long long lastStats[16] = {};   // rt_count_rays diagnostics (rt_debug_stats)
+    unsigned long long lastStats[32] = {};   // rt_count_rays diagnostics (rt_debug_stats)
     // cost-feedback tile scheduling state (packet kernel)
     // Frames may be issued on several streams (frames in flight overlapping on the device), so the order is
     // double-buffered: a sort writes the buffer no launch is reading, and later launches wait for it.
@@ -350,7 +350,7 @@ int rt_create(rt_context **out, int deviceId) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
         hipEventCreateWithFlags(&c->evScene, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&c->dRayCounter, 16 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void **)&c->dRayCounter, 32 * sizeof(unsigned long long)) != hipSuccess) {
         rt_destroy(c);
         return RT_ERR_HIP;
     }
@@ -545,14 +545,14 @@ static int count_rays_impl(rt_context *c, const rt_params *p, uint64_t *rays, in
     hipError_t e2 = hipMalloc((void **)&nrm, n * sizeof(uint2));
     if (e1 == hipSuccess && e2 == hipSuccess) {
         rc = RT_OK;
-        if (hipMemsetAsync(c->dRayCounter, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = RT_ERR_HIP;
+        if (hipMemsetAsync(c->dRayCounter, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = RT_ERR_HIP;
         if (!rc) rc = launch(c, p, col, pos, nrm, c->dRayCounter, c->stream, false, countMode);
-        unsigned long long v[16] = {};
+        unsigned long long v[32] = {};
         if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess ||
                     hipMemcpy(v, c->dRayCounter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess))
             rc = fail(c, RT_ERR_HIP, "ray counter readback");
         *rays = v[0];
-        for (int k = 0; k < 16; k++) c->lastStats[k] = v[k];
+        for (int k = 0; k < 32; k++) c->lastStats[k] = v[k];
     } else {
         rc = fail(c, RT_ERR_HIP, "hipMalloc (ray count scratch)", e1 != hipSuccess ? e1 : e2);
     }
@@ -577,9 +577,9 @@ int rt_debug_stats(rt_context *c, uint64_t out[4]) {
     return RT_OK;
 }
 
-int rt_debug_stats_ex(rt_context *c, uint64_t out[16]) {
+int rt_debug_stats_ex(rt_context *c, uint64_t out[32]) {
     if (!c || !out) return RT_ERR_INVALID_ARG;
-    for (int k = 0; k < 16; k++) out[k] = c->lastStats[k];
+    for (int k = 0; k < 32; k++) out[k] = c->lastStats[k];
     return RT_OK;
 }
 

@@ -415,7 +415,7 @@ class RayTracer:
         return list(out)
 
     def debug_stats_ex(self):
-        out = (ctypes.c_uint64 * 16)()
+        out = (ctypes.c_uint64 * 32)()
         self._check(self.lib.rt_debug_stats_ex(self.ctx, out), "rt_debug_stats_ex")
         return list(out)
 

@@ -1,6 +1,6 @@
 """Build macro variants of the library ON the GPU box and time them at the configs' full sizes in one gpurun call,
 checking every variant's three surfaces against the first variant's bit for bit.
-usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH]"""
+usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH] [--pcf=N]"""
 import os, re, subprocess, sys, zlib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -18,6 +18,8 @@ if os.environ.get("RT_TRY_CHILD"):
         sc = scenes.make_scene(cfg, host.generate_aabb)
         w, h = (int(v) for v in size.split("x")) if size else (sc.width, sc.height)
         p = sc.params(width=w, height=h)
+        if "pcf" in opt:
+            sc.lights["pcfSamples"] = int(opt["pcf"])
         rt.load(sc)
         for _ in range(3):
             rt.render(p); rt.sync()
