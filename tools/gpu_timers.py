@@ -16,7 +16,9 @@ if os.environ.get("RT_TIMERS_CHILD"):
         print(f"C{cfg} {sc.width}x{sc.height}: traced rays {rays} packets {s[1]} cand/packet {s[2] / max(s[1], 1):.1f} | wave time: "
               f"closest {s[12] / tot:.3f}  light packet+masks {s[13] / tot:.3f}  pcf samples {s[14] / tot:.3f}  "
               f"rest {1 - (s[12] + s[13] + s[14]) / tot:.3f} | of the light section: set-up {s[16] / tot:.3f}, masks of split packets {s[17] / tot:.3f}; "
-              f"split / unsplit light packets {s[18]} / {s[19]}", flush=True)
+              f"split / unsplit light packets {s[18]} / {s[19]} | sample groups {s[25]}, candidate trips {s[22]} ({s[22] / max(s[25], 1):.1f} per group), "
+              f"with a lane passing the slab test {s[23]} ({s[23] / max(s[22], 1):.3f}), lanes passing per such trip {s[24] / max(s[23], 1):.1f}; "
+              f"wave clocks per sample group {s[14] / max(s[25], 1):.0f}", flush=True)
     sys.exit(0)
 from opengl_raytracing_amd import build as B
 os.makedirs("/tmp/rtx", exist_ok=True)
