@@ -194,7 +194,9 @@ int rt_debug_stats(rt_context *ctx, uint64_t out[4]);
  * waves; zero otherwise): closest-hit traversals, a light's packet + candidate masks, its PCF sample loops, the whole wave,
  * the light packet's set-up alone, masks of octant-split light packets, split / unsplit light packets; out[20] / out[21]
  * candidates entering / leaving the per-lane cull level of a light's PCF rays; timers build only: out[22] candidate trips of
- * the PCF sample loops, out[23] those in which some lane passes the slab test, out[24] lanes passing, out[25] sample groups. */
+ * the PCF sample loops, out[23] those in which some lane passes the slab test, out[24] lanes passing, out[25] sample groups, out[26] the whole
+ * light loop, out[27] the subsurface section, out[28] PCSS blocker searches, out[29] hit shading set-up, out[30] roulette + next
+ * direction (clocks). */
 int rt_debug_stats_ex(rt_context *ctx, uint64_t out[32]);
 /* Measured cost (shader clock cycles / 64, summed over the tile's waves) of every workgroup tile of the
  * last feedback-scheduled rt_render / rt_render_to launch, in raster tile order; synchronises.  Writes up

@@ -227,6 +227,21 @@ def test_pcf_sample_counts_and_shadow_types(tracer, host, oracle):
         assert_bit_exact(render_gpu(tracer, sc, p), oracle.render(sc, p), f"pcf {samples} type {stype}")
 
 
+@pytest.mark.parametrize("cfg,samples", [(4, 8), (4, 16), (5, 9), (5, 16)])
+def test_many_pcf_samples_in_many_object_scenes(tracer, host, oracle, cfg, samples):
+    """From 8 samples per light on, the many-object kernel profile refines each light's candidate mask per LANE before the
+    sample loops (rt_packet.inc, RT_PK_CONE): C4's / C5's scenes with 8 / 9 / 16 PCF samples, and with a softness near the
+    bound where the jitter interval swallows whole direction components (filterSize 0.15 of the 0.2 limit)."""
+    sc = scenes.make_scene(cfg, host.generate_aabb)
+    sc.lights["pcfSamples"] = samples
+    p = sc.params(width=80, height=48)
+    assert_bit_exact(render_gpu(tracer, sc, p), oracle.render(sc, p), f"C{cfg} pcf {samples}")
+    sc.lights["shadowSoftness"] = 30.0
+    sc.lights["type"][1] = L.DIRECTIONAL
+    sc.lights["type"][2] = L.POINT
+    assert_bit_exact(render_gpu(tracer, sc, p), oracle.render(sc, p), f"C{cfg} pcf {samples}, wide jitter, mixed light types")
+
+
 def test_noise_skybox_and_framecount(tracer, host, oracle):
     """Noise texture bound / unbound, frameCount > 0, skybox on / off, non-power-of-two noise."""
     sc = scenes.make_scene(3, host.generate_aabb)

@@ -18,7 +18,10 @@ if os.environ.get("RT_TIMERS_CHILD"):
               f"rest {1 - (s[12] + s[13] + s[14]) / tot:.3f} | of the light section: set-up {s[16] / tot:.3f}, masks of split packets {s[17] / tot:.3f}; "
               f"split / unsplit light packets {s[18]} / {s[19]} | sample groups {s[25]}, candidate trips {s[22]} ({s[22] / max(s[25], 1):.1f} per group), "
               f"with a lane passing the slab test {s[23]} ({s[23] / max(s[22], 1):.3f}), lanes passing per such trip {s[24] / max(s[23], 1):.1f}; "
-              f"wave clocks per sample group {s[14] / max(s[25], 1):.0f}", flush=True)
+              f"wave clocks per sample group {s[14] / max(s[25], 1):.0f} | light loop {s[26] / tot:.3f} (of which PCSS blocker search {s[28] / tot:.3f}, "
+              f"shading + light set-up {(s[26] - s[13] - s[14] - s[28]) / tot:.3f}), subsurface {s[27] / tot:.3f}, "
+              f"hit shading set-up {s[29] / tot:.3f}, roulette + next direction {s[30] / tot:.3f}, "
+              f"ray generation + sky + stores {1 - (s[12] + s[26] + s[27] + s[29] + s[30]) / tot:.3f}", flush=True)
     sys.exit(0)
 from opengl_raytracing_amd import build as B
 os.makedirs("/tmp/rtx", exist_ok=True)
