@@ -23,6 +23,7 @@ struct rt_context {
     float4 *dCompiled = nullptr;
     size_t capCompiledF4 = 0;
     int nObj = 0, nLt = 0;
+    bool anyPcss = false;               // some light of the current scene has shadowType 2 (selects the kernel instantiation)
     // double-buffered pinned staging so rt_set_scene never blocks on the GPU and the caller's
     // bytes are consumed before it returns (glBufferData semantics)
     uint8_t *hStage[2] = {nullptr, nullptr};
@@ -162,6 +163,7 @@ void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
     }
     f->nObj = c->nObj;
     f->nLt = c->nLt;
+    f->anyPcss = c->anyPcss ? 1 : 0;
     f->noiseW = c->noiseW;
     f->noiseH = c->noiseH;
     f->skySize = c->skySize;
@@ -422,6 +424,12 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     HIP_TRY(c, hipEventRecord(c->evScene, c->stream));   // foreign streams order behind this (rt_render_to)
     c->nObj = nObj;
     c->nLt = nLt;
+    c->anyPcss = false;
+    for (int i = 0; i < nLt; i++) {
+        rt_light l;
+        memcpy(&l, (const uint8_t *)lights + (size_t)i * RT_LIGHT_STRIDE, sizeof l);
+        c->anyPcss = c->anyPcss || l.shadowType == 2;
+    }
     return RT_OK;
 }
 

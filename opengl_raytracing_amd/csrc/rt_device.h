@@ -19,6 +19,7 @@ struct RtFrame {
     rt_params p;
     int32_t nObj, nLt;
     int32_t noiseW, noiseH, skySize;
+    int32_t anyPcss;                    // some light has shadowType 2: kernel instantiation with paired blocker rays
     float sx, sy;                       // (aspect*tanFov)*focalLength, tanFov*focalLength
     // cosineWeightedHemisphere's local direction for the bounce at each depth
     // (identical for every pixel: hammersley(depth*64+frameCount, 64))

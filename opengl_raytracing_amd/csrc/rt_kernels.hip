@@ -690,7 +690,7 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
 #define RT_PK_LIGHT_SCENE 32    // objects: at or below, the LIGHT profile
 #endif
 template <int COUNT, int BT, bool COMPACT, typename PROFILE>
-__global__ __launch_bounds__(BT, RT_PK_WAVES_SMALL)
+__global__ __launch_bounds__(BT, PROFILE::waves)
 void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *__restrict__ gColor,
                              float4 *__restrict__ gPosition, uint2 *__restrict__ gNormal,
                              unsigned long long *rayCounter) {
@@ -864,9 +864,15 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
             else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);            \
             else hipLaunchKernelGGL((rt_render_packet_kernel<0, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);                             \
         } while (0)
-        if (light) RT_LAUNCH_PK(64, PkLight);
-        else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1);
-        else RT_LAUNCH_PK(64, PkHeavy);
+        if (f.anyPcss) {
+            if (light) RT_LAUNCH_PK(64, PkLightS);
+            else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1S);
+            else RT_LAUNCH_PK(64, PkHeavyS);
+        } else {
+            if (light) RT_LAUNCH_PK(64, PkLight);
+            else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1);
+            else RT_LAUNCH_PK(64, PkHeavy);
+        }
 #undef RT_LAUNCH_PK
     } else {
         dim3 grid((f.p.regionW + TILE - 1) / TILE, (f.p.regionH + TILE - 1) / TILE);
