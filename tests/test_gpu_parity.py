@@ -317,6 +317,22 @@ def test_strip_tiling_equals_single_render(tracer, host):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
 
+@pytest.mark.parametrize("cfg", [2, 4])
+def test_shadow_type_switches_the_kernel_instantiation_per_scene(tracer, host, oracle, cfg):
+    """rt_set_scene picks the kernel instantiation with grouped PCSS blocker rays when any light has shadowType 2
+    (rt_abi.cpp: anyPcss) and the PCF-only one otherwise: PCF -> one PCSS light among PCF lights -> all PCSS -> PCF again on one
+    context, each frame against the oracle (few- and many-object profiles)."""
+    sc = scenes.make_scene(cfg, host.generate_aabb)
+    p = sc.params(width=96, height=54)
+    for types in ([L.SHADOW_PCF] * len(sc.lights), None, [L.SHADOW_PCSS] * len(sc.lights), [L.SHADOW_PCF] * len(sc.lights)):
+        if types is None:
+            sc.lights["shadowType"] = L.SHADOW_PCF
+            sc.lights["shadowType"][len(sc.lights) // 2] = L.SHADOW_PCSS
+        else:
+            sc.lights["shadowType"] = types
+        assert_bit_exact(render_gpu(tracer, sc, p), oracle.render(sc, p), f"C{cfg} shadow types {list(sc.lights['shadowType'])}")
+
+
 def test_scene_update_every_frame_and_timing(tracer, host, oracle):
     """The reference re-uploads both SSBOs every frame (ImGUIManager.cpp:202,338): back-to-back
     set_scene/render pairs must each see their own scene; the timing hook returns a duration."""
