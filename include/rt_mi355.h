@@ -203,6 +203,14 @@ int rt_debug_stats_ex(rt_context *ctx, uint64_t out[32]);
  * to cap entries, *nTiles / *tilesX describe the tile grid.  Measurement hook, no reference counterpart. */
 int rt_debug_tile_costs(rt_context *ctx, unsigned *out, int cap, int *nTiles, int *tilesX);
 
+/* The lights' SHADOW TABLES of the current scene (built by rt_set_scene for scenes of <= 256 objects; csrc/rt_shadowtab.inc):
+ * per light 24 dwords of header -- (kind, base dword, K, NB) (invBinW, binMax, wlo, nmax^2) (pmin, qmin, invCell, cells)
+ * (T0, eta) (B0, nmax) (light position or direction, binW); kind 0 no table, 1 cube map x distance bins (point / area),
+ * 2 planar grid x depth bins (directional) -- followed by the cells, *wordsPerCell dwords each, bit i = object i may
+ * occlude a PCF ray of a shading point that reads the cell.  out == NULL only queries *nDwords.  Test hook
+ * (tests/test_shadow_tables.py checks the tables against brute-force rays); synchronises.  No reference counterpart. */
+int rt_debug_shadow_tables(rt_context *ctx, uint32_t *out, size_t capDwords, size_t *nDwords, int *wordsPerCell);
+
 /* The GL driver's own sin / cos / tan / exp as the path evaluates them (csrc/rt_mesa_math.h: tan(radians(fov)/2) of
  * raytracingCs.glsl:209, cos/sin of :296-298, sin of random() :274, exp of :334), host side: out[4i..4i+3] =
  * sin, cos, tan, exp of in[i].  Test hook (no GPU needed), no reference counterpart. */

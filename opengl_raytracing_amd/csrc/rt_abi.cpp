@@ -75,6 +75,11 @@ struct rt_context {
     int frameW = 0, frameH = 0, lastHistory = -1;
     bool frameAOValid = false;
     size_t capBloomPx = 0;
+    // shadow tables of the current scene (rt_shadowtab.inc)
+    unsigned *dShadowTab = nullptr;
+    size_t capShadowTab = 0;
+    bool shadowTabValid = false;
+    RtShadowTabGeom stGeomSmall = {32, 64, 24}, stGeomLarge = {16, 32, 24};      // <= 32 objects / more (RT_ST_GEOM overrides both)
     bool feedback = true;
     unsigned fbPeriod = 32;                    // re-sort period in frames (RT_FB_PERIOD overrides, for measurements)
     std::string err;
@@ -231,6 +236,7 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
     sc.sky = c->dSky;
     sc.tileOrder = nullptr;
     sc.tileCost = nullptr;
+    sc.shadowTab = c->shadowTabValid ? c->dShadowTab : nullptr;
     if (!c->dCompiled) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene has not been called");
     // Longest-first tile order from the previous frames' measured tile costs (same window geometry, any
     // stream).  The first frame of a geometry runs in raster order and only records costs.
@@ -349,6 +355,11 @@ int rt_create(rt_context **out, int deviceId) {
         const int v = atoi(e);
         if (v >= 1 && v <= 1024) c->fbPeriod = (unsigned)v;
     }
+    if (const char *e = getenv("RT_ST_GEOM")) {        // "Kcube,Kplan,NB": measurement override of the shadow-table geometry
+        int kc = 0, kp = 0, nb = 0;
+        if (sscanf(e, "%d,%d,%d", &kc, &kp, &nb) == 3 && kc >= 4 && kc <= 128 && kp >= 4 && kp <= 256 && nb >= 1 && nb <= 128)
+            c->stGeomSmall = c->stGeomLarge = RtShadowTabGeom{kc, kp, nb};
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
         hipEventCreateWithFlags(&c->evScene, hipEventDisableTiming) != hipSuccess ||
@@ -369,7 +380,7 @@ int rt_destroy(rt_context *c) {
             (void)hipEventSynchronize(c->fbStreams[i].last);
             (void)hipEventDestroy(c->fbStreams[i].last);
         }
-    void *bufs[] = {c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
+    void *bufs[] = {c->dShadowTab, c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
                     c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1], c->dSsaoDepth, c->dFrameAO[0], c->dFrameAO[1], c->dHistory[0], c->dHistory[1], c->dFrameDisplay};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -421,6 +432,14 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     HIP_TRY(c, hipEventRecord(c->evStage[k], c->stream));
     c->stageUsed[k] = true;
     HIP_TRY(c, rt_launch_compile_scene(c->dObjects, nObj, c->dLights, nLt, c->dCompiled, c->stream));
+    // the lights' shadow tables of this scene (light-space candidate masks, rt_shadowtab.inc)
+    c->shadowTabValid = false;
+    if (nObj > 0 && nLt > 0 && nObj <= RT_ST_MAX_OBJECTS) {
+        const RtShadowTabGeom &g = nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
+        if ((rc = ensure(c, &c->dShadowTab, &c->capShadowTab, rt_shadowtab_dwords(g, nObj, nLt)))) return rc;
+        HIP_TRY(c, rt_launch_shadow_tables(c->dCompiled, nObj, nLt, c->dShadowTab, g, c->stream));
+        c->shadowTabValid = true;
+    }
     HIP_TRY(c, hipEventRecord(c->evScene, c->stream));   // foreign streams order behind this (rt_render_to)
     c->nObj = nObj;
     c->nLt = nLt;
@@ -588,6 +607,23 @@ int rt_debug_stats(rt_context *c, uint64_t out[4]) {
 int rt_debug_stats_ex(rt_context *c, uint64_t out[32]) {
     if (!c || !out) return RT_ERR_INVALID_ARG;
     for (int k = 0; k < 32; k++) out[k] = c->lastStats[k];
+    return RT_OK;
+}
+
+int rt_debug_shadow_tables(rt_context *c, uint32_t *out, size_t capDwords, size_t *nDwords, int *wordsPerCell) {
+    if (!c || !nDwords) return RT_ERR_INVALID_ARG;
+    *nDwords = 0;
+    if (wordsPerCell) *wordsPerCell = 0;
+    if (!c->shadowTabValid) return RT_OK;
+    const RtShadowTabGeom &g = c->nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
+    const size_t n = rt_shadowtab_dwords(g, c->nObj, c->nLt);
+    *nDwords = n;
+    if (wordsPerCell) *wordsPerCell = rt_shadowtab_words(c->nObj);
+    if (!out) return RT_OK;
+    if (capDwords < n) return fail(c, RT_ERR_TOO_LARGE, "buffer smaller than the shadow tables");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->dShadowTab, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -36,7 +36,23 @@ struct RtDeviceScene {
     // into the longest-first order of frame k+1.  Pure scheduling: no pixel value depends on it.
     const unsigned *tileOrder;
     unsigned *tileCost;
+    // Shadow tables (rt_shadowtab.inc): per light RT_ST_HDR_F4 float4 of header, then the lights' cells (one bit per object);
+    // built by rt_set_scene for scenes of <= RT_ST_MAX_OBJECTS objects, nullptr otherwise.
+    const unsigned *shadowTab;
 };
+
+#define RT_ST_HDR_F4 6            // float4 per light header
+#define RT_ST_MAX_OBJECTS 256     // 8 dwords per cell
+// dwords per cell for a scene of nObj objects (the packet kernel's profiles are compiled for exactly these: rt_packet.inc)
+static inline int rt_shadowtab_words(int nObj) { return nObj <= 32 ? 1 : (nObj <= 64 ? 2 : 8); }
+// Table geometry: cube-map cells per face edge (point / area lights), grid cells per axis (directional), bins; and the
+// buffer size in dwords that holds any mix of light types.
+struct RtShadowTabGeom { int Kcube, Kplan, NB; };
+static inline size_t rt_shadowtab_dwords(const RtShadowTabGeom &g, int nObj, int nLt) {
+    const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
+    return (size_t)nLt * RT_ST_HDR_F4 * 4 + (size_t)nLt * (cube > plan ? cube : plan) * rt_shadowtab_words(nObj) + 4;
+}
+hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s);
 
 #define RT_PCF_TAB_N 16      // PCF samples tabulated per directional light (UI range of pcfSamples is 1..16)
 // float4 count of the whole compiled buffer: the staged part (rt_compiled_f4) + per light RT_PCF_TAB_N x 2 float4

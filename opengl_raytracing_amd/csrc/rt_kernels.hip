@@ -102,6 +102,7 @@ struct SceneLds {
     bool keepAabb = true;       // packet kernel profile: chunk 0's AABB lives in the lane's VGPRs (else re-read from LDS per cull pass)
     int hotStride = RT_HOT_F4, matF4Base = 0;
     int pcfTabF4 = -1;          // float4 index in `global` of the directional lights' PCF ray tables, -1 = not usable (noise bound)
+    const unsigned *stab = nullptr;        // shadow tables (rt_shadowtab.inc): per-light headers, then the cells
 };
 
 // haltonSequence (raytracingCs.glsl:278-288); used by the scene compiler and as the
@@ -459,6 +460,7 @@ __device__ __forceinline__ float random2(float sx, float sy) {
     return fract(det_sinf(d) * 43758.5453123f);
 }
 
+#include "rt_shadowtab.inc"
 #include "rt_packet.inc"
 
 }  // namespace
@@ -722,6 +724,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     sc.haltonFloatBase = (sc.lgtF4Base + f.nLt * RT_LGT_F4) * 4;
     sc.park = (float *)(lds + nF4 + 1);      // after the staged scene and the 16-byte counter slot
     sc.pcfTabF4 = dsc.noise ? -1 : nAll;     // the tables follow the staged sections in the global copy
+    sc.stab = dsc.shadowTab;
 
     // tile of this workgroup: longest-first order from the previous frame's measured costs, if any
     constexpr int TILE_ = (BT == 256) ? 16 : 8;
@@ -843,6 +846,22 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
     return hipGetLastError();
 }
 
+// Shadow tables of the current compiled scene (rt_shadowtab.inc): headers by one workgroup, then one thread per cell.
+#ifndef RT_ST_NMAX
+#define RT_ST_NMAX 8.0f         // lanes whose shading normal is longer take every object (the tables' aim-error bound assumes |N| <= this)
+#endif
+hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s) {
+    if (nLt <= 0 || nObj <= 0 || nObj > RT_ST_MAX_OBJECTS) return hipSuccess;
+    const int NW = rt_shadowtab_words(nObj);
+    hipLaunchKernelGGL(rt_shadowtab_headers_kernel, dim3(1), dim3(RT_MAX_LIGHTS), 0, s, dCompiled, nObj, nLt, (float4 *)dTab, g.Kcube, g.Kplan,
+                       g.NB, NW, RT_ST_NMAX);
+    const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
+    const size_t maxCells = cube > plan ? cube : plan;
+    hipLaunchKernelGGL(rt_shadowtab_build_kernel, dim3((unsigned)((maxCells + 255) / 256), (unsigned)nLt), dim3(256), 0, s, dCompiled, nObj, nLt,
+                       (const float4 *)dTab, dTab, NW);
+    return hipGetLastError();
+}
+
 // countMode (only with dRayCounter): 1 = instrumented build that traces every ray the REFERENCE traces (its count is the
 // unit count R of the metric), 2 = instrumented build that keeps the production kernel's provably-dead-ray skips
 // (its count is what the timed kernel actually traverses).
@@ -864,14 +883,17 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
             else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);            \
             else hipLaunchKernelGGL((rt_render_packet_kernel<0, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);                             \
         } while (0)
+        if (PkLight::tabWords > 0 && !sc.shadowTab && f.nObj > 0 && f.nLt > 0 && f.nObj <= RT_ST_MAX_OBJECTS) return hipErrorInvalidValue;     // (rt_set_scene builds them)
         if (f.anyPcss) {
             if (light) RT_LAUNCH_PK(64, PkLightS);
             else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1S);
-            else RT_LAUNCH_PK(64, PkHeavyS);
+            else if (f.nObj <= RT_ST_MAX_OBJECTS) RT_LAUNCH_PK(64, PkHeavyS);
+            else RT_LAUNCH_PK(64, PkHugeS);
         } else {
             if (light) RT_LAUNCH_PK(64, PkLight);
             else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1);
-            else RT_LAUNCH_PK(64, PkHeavy);
+            else if (f.nObj <= RT_ST_MAX_OBJECTS) RT_LAUNCH_PK(64, PkHeavy);
+            else RT_LAUNCH_PK(64, PkHuge);
         }
 #undef RT_LAUNCH_PK
     } else {

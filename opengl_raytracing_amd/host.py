@@ -34,7 +34,7 @@ EXPORTS = [
     "rt_count_rays", "rt_count_rays_traced", "rt_debug_stats", "rt_debug_stats_ex", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
     "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_frame", "rt_frame_surfaces", "rt_strip_local_rows", "rt_deinterleave",
-    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack", "rt_debug_mesa_math",
+    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack", "rt_debug_mesa_math", "rt_debug_shadow_tables",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library(build_if_missing=True):
     lib.rt_wire_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.rt_wire_unpack.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.rt_debug_mesa_math.argtypes = [vp, vp, ci]
+    lib.rt_debug_shadow_tables.argtypes = [vp, vp, ctypes.c_size_t, P(ctypes.c_size_t), P(ci)]
     for name in EXPORTS:
         if name != "rt_last_error":
             getattr(lib, name).restype = ci
@@ -408,6 +409,16 @@ class RayTracer:
     def ssao_blur(self, d_in, d_out, width, height, horizontal=False, stream=None):
         self._check(self.lib.rt_ssao_blur(self.ctx, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), width, height,
                                           int(bool(horizontal)), ctypes.c_void_p(stream) if stream else None), "rt_ssao_blur")
+
+    def shadow_tables(self):
+        """(dwords uint32[n], words per cell) of the current scene's shadow tables (headers + cells), or (None, 0)."""
+        n, w = ctypes.c_size_t(0), ctypes.c_int(0)
+        self._check(self.lib.rt_debug_shadow_tables(self.ctx, None, 0, ctypes.byref(n), ctypes.byref(w)), "rt_debug_shadow_tables")
+        if n.value == 0:
+            return None, 0
+        out = np.zeros(n.value, dtype=np.uint32)
+        self._check(self.lib.rt_debug_shadow_tables(self.ctx, _ptr(out), n.value, ctypes.byref(n), ctypes.byref(w)), "rt_debug_shadow_tables")
+        return out, w.value
 
     def debug_stats(self):
         out = (ctypes.c_uint64 * 4)()

@@ -1,6 +1,8 @@
 """Build macro variants of the library ON the GPU box and time them at the configs' full sizes in one gpurun call,
 checking every variant's three surfaces against the first variant's bit for bit.
-usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH] [--pcf=N]"""
+usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH] [--pcf=N]
+A spec "name:@path/to/lib.so" takes a library prebuilt in the build container (tools/build_variants.py -> exp/) instead of
+compiling on the box (box time is GPU budget)."""
 import os, re, subprocess, sys, zlib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -42,10 +44,14 @@ ref = {}
 for spec in specs:
     name, _, flags = spec.partition(":")
     out = f"/tmp/rtx/lib_{name}.so"
+    if flags.startswith("@"):
+        out = os.path.abspath(flags[1:])
+        if not os.path.exists(out):
+            print(f"[{name}] missing {out}", flush=True); continue
     srcs = [os.path.join(B.CSRC, s_) for s_ in B.SOURCES]
     cmd = [B._hipcc(), *B.HIPCC_FLAGS, *flags.split(), "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(REPO, "include"),
            "-I", B.CSRC, "-x", "hip", *srcs, "-o", out]
-    cr = subprocess.run(cmd, capture_output=True, text=True)
+    cr = subprocess.run(cmd, capture_output=True, text=True) if not flags.startswith("@") else subprocess.CompletedProcess(cmd, 0, "", "")
     if cr.returncode:
         print(f"[{name}] BUILD FAILED {cr.stderr[-600:]}", flush=True); continue
     for b_ in cr.stderr.split("Function Name: "):
