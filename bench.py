@@ -28,9 +28,16 @@ Rank 0 prints ONE JSON line.  What the fields mean (VERDICT r1 asked for a recor
   lives in LDS / SGPRs); `wasted_traffic_ratio` = traffic / compulsory bytes (surfaces + inputs).
 * `algorithmic_equiv` = SURVEY.md 8(d)'s algorithmic bytes (the 176 B/object/ray stream the reference shader
   reads) / kernel time: an EQUIVALENT rate with no fraction -- that stream is served on chip by design.
-* `free_running` = the same workload with frameCount advancing every frame (the reference's default: TAA on,
-  ForwardShadingPipeline.cpp:254), where the tile-cost feedback cannot predict the next frame perfectly;
-  `cold_frame_ms` = raster order, no feedback at all.
+* `frame_ms` = per-frame distribution of the timed region (every frame bracketed by its own HIP events on the launch
+  stream): median / p10 / p90 / min / max.  `ms_per_step` stays the mean the driver checks; `step_ms_device` is the
+  same region by its first and last event, and the duration `roofline.frac` is computed from.
+* The headline frames are identical, so from the third on they run in the order sorted from their MEASURED tile costs.
+  `free_running` = the same workload with frameCount advancing every frame (the reference's default: TAA on,
+  ForwardShadingPipeline.cpp:254): every frame's inputs are new, its tile order is PREDICTED from them in-stream
+  (rt_predict_tiles_kernel), no history is used.  `cold_frame_ms` = such new frames one at a time with a device sync
+  in between (nothing overlaps, predictor pass included); `raster_order_ms` = the scheduler switched off.
+* `pipelined` = the headline frames with two in flight on two streams (the ABI is asynchronous): frame k's tail
+  overlaps frame k+1's head.  Throughput, not latency.
 * `cpu_baseline` = the oracle port timed on this box's host cores; `cpu_baseline_reference` = the reference's own
   GLSL on Mesa llvmpipe (static record produced by tools/time_reference_llvmpipe.py in the build container --
   /root/reference cannot travel to the GPU box).
@@ -102,16 +109,17 @@ def workload_name(cfg, sc):
             (", skybox" if sc.use_skybox else ""))
 
 
-def roofline_record(cfg, sc, n_px, rays_ref, kernel_ms, counters, src_hash):
-    """The roofline / traffic objects of one config from the live kernel time and the committed PMC record."""
-    ks = kernel_ms * 1e-3
+def roofline_record(cfg, sc, n_px, rays_ref, step_ms, counters, src_hash):
+    """The roofline / traffic objects of one config from the live duration of a step (HIP events over the timed region) and the
+    committed PMC record."""
+    ks = step_ms * 1e-3
     n_obj, n_lt = len(sc.objects), len(sc.lights)
     compulsory = n_px * 40 + n_obj * 176 + n_lt * 96 + (n_px if sc.noise is not None else 0)
     b_alg = algorithmic_bytes(rays_ref, n_obj, n_lt, n_px, sc.noise is not None, 0)
     out = {}
     traffic = None
     if counters:
-        stale = counters.get("src_hash") not in (None, src_hash)
+        stale = counters.get("src_hash") != src_hash          # a record without a hash is NOT tied to this build
         insts = counters.get("SQ_INSTS_VALU")
         if counters.get("fetch_size_kb") is not None and counters.get("write_size_kb") is not None:
             traffic = int((2 * counters["fetch_size_kb"] + counters["write_size_kb"]) * 1024)
@@ -169,31 +177,30 @@ def measure_single(cfg, steps, warmup, variant, dev_index, with_modes=True):
     for _ in range(warmup):
         render(base)
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the timed region: K frames, each between two events on the launch stream (K + 1 events)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(steps):
+    for i in range(steps):
+        evs[i].record(stream)
         render(base)
-    ev1.record(stream)
+    evs[steps].record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # dominant kernel's average launch duration: HIP events on the launch stream, kernel launches only
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record(stream)
-    for _ in range(steps):
-        render(base)
-    k1.record(stream)
-    torch.cuda.synchronize()
+    per_frame = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
     res = dict(sc=sc, W=W, H=H, rays_ref=rays_ref, rays_traced=rays_traced, elapsed=elapsed,
-               step_ms_dev=ev0.elapsed_time(ev1) / steps, kernel_ms=k0.elapsed_time(k1) / steps)
+               step_ms_dev=evs[0].elapsed_time(evs[steps]) / steps,
+               frame_ms={"median": round(float(np.median(per_frame)), 4), "p10": round(float(np.percentile(per_frame, 10)), 4),
+                         "p90": round(float(np.percentile(per_frame, 90)), 4), "min": round(float(per_frame.min()), 4),
+                         "max": round(float(per_frame.max()), 4)})
     if with_modes:
-        # (1) frameCount advancing every frame, as in the reference with TAA on: rays differ per frame, so count each
+        # (1) frameCount advancing every frame, as in the reference with TAA on: every frame is new (predicted order, no history);
+        #     the rays differ per frame, so count each
         n_free = min(steps, 64)
         fc0 = sc.frame_count
-        frames = [L.copy_params(base, frameCount=fc0 + k) for k in range(n_free)]
+        frames = [L.copy_params(base, frameCount=fc0 + 1 + k) for k in range(n_free)]
         free_rays = [rt.count_rays(p) for p in frames]
-        for k in range(64):                       # let the accumulated tile costs describe the rotating sample
-            render(L.copy_params(base, frameCount=fc0 + 1000 + k))
+        for p in frames[:8]:
+            render(p)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for p in frames:
@@ -203,11 +210,22 @@ def measure_single(cfg, steps, warmup, variant, dev_index, with_modes=True):
         res["free_running"] = {"ms_per_step": round(t_free / n_free * 1e3, 4), "frames": n_free,
                                "value_mray_s": round(sum(free_rays) / t_free / 1e6, 1),
                                "rays_reference_per_frame_min_max": [int(min(free_rays)), int(max(free_rays))],
-                               "note": "frameCount advances every frame (reference default, TAA on: "
-                                       "ForwardShadingPipeline.cpp:254); it rotates the bounce sample all pixels share"}
-        # (2) no feedback at all: raster tile order (what the very first frame of a new view costs)
+                               "note": "frameCount advances every frame (reference default, TAA on: ForwardShadingPipeline.cpp:254): it "
+                                       "rotates the bounce sample all pixels share, every frame's inputs are new and its tile order is "
+                                       "predicted from them (no history)"}
+        # (2) the same new frames one at a time (device sync in between): what the first frame of a new view costs, predictor included
+        n_cold = max(4, min(steps, 16))
+        lat = []
+        for p in frames[:n_cold]:
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            render(p)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - c0) * 1e3)
+        res["cold_frame_ms"] = round(float(np.mean(lat)), 4)
+        res["cold_frame_rays_reference_mean"] = int(np.mean(free_rays[:n_cold]))
+        # (3) scheduler off: raster tile order, the headline frame
         rt.set_variant((variant & 0xff) | 0x100)
-        n_cold = max(4, min(steps, 20))
         for _ in range(2):
             render(base)
         torch.cuda.synchronize()
@@ -215,8 +233,28 @@ def measure_single(cfg, steps, warmup, variant, dev_index, with_modes=True):
         for _ in range(n_cold):
             render(base)
         torch.cuda.synchronize()
-        res["cold_frame_ms"] = round((time.perf_counter() - t0) / n_cold * 1e3, 4)
+        res["raster_order_ms"] = round((time.perf_counter() - t0) / n_cold * 1e3, 4)
         rt.set_variant(variant)
+        # (4) two frames in flight on two streams (headline frames)
+        s2 = torch.cuda.Stream(device=dev)
+        buf2 = D.alloc_rank_buffer(one, dev)
+        col2, pos2, nrm2 = D.surface_views(buf2, one)
+        targets = [(stream, (col, pos, nrm)), (s2, (col2, pos2, nrm2))]
+
+        def render2(k):
+            st, (c_, q_, n_) = targets[k & 1]
+            rt.render_to(base, c_.data_ptr(), q_.data_ptr(), n_.data_ptr(), stream=st.cuda_stream)
+        for k in range(max(8, warmup)):
+            render2(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            render2(k)
+        torch.cuda.synchronize()
+        t_pipe = time.perf_counter() - t0
+        res["pipelined"] = {"frames_in_flight": 2, "ms_per_step": round(t_pipe / steps * 1e3, 4),
+                            "value_mray_s": round(rays_ref * steps / t_pipe / 1e6, 1),
+                            "note": "the same frames, two in flight on two streams: throughput, not latency"}
     rt.close()
     return res
 
@@ -229,9 +267,10 @@ def single_record(cfg, r, steps, warmup, src_hash):
            "mray_s_traced": round(r["rays_traced"] * steps / r["elapsed"] / 1e6, 1),
            "mpx_per_s": round(n_px * steps / r["elapsed"] / 1e6, 1),
            "rays_reference_per_frame": r["rays_ref"], "rays_traced_per_frame": r["rays_traced"],
-           "kernel_ms": round(r["kernel_ms"], 4), "step_ms_device": round(r["step_ms_dev"], 4)}
-    out.update(roofline_record(cfg, sc, n_px, r["rays_ref"], r["kernel_ms"], load_counters(cfg), src_hash))
-    for k in ("free_running", "cold_frame_ms"):
+           "step_ms_device": round(r["step_ms_dev"], 4), "frame_ms": r["frame_ms"]}
+    # the roofline's duration is the timed region's own (the one `value` is computed from), by HIP events on the launch stream
+    out.update(roofline_record(cfg, sc, n_px, r["rays_ref"], r["step_ms_dev"], load_counters(cfg), src_hash))
+    for k in ("free_running", "cold_frame_ms", "cold_frame_rays_reference_mean", "raster_order_ms", "pipelined"):
         if k in r:
             out[k] = r[k]
     return out
@@ -249,7 +288,7 @@ def main():
     ap.add_argument("--no-modes", action="store_true",
                     help="N = 1: skip the free-running-frameCount and raster-order (cold) measurements, so that every launch of the "
                          "dominant kernel in the process belongs to the headline loop (profiles/run_profile.sh uses this: "
-                         "rocprofv3's per-kernel average is then the headline kernel_ms)")
+                         "rocprofv3's per-kernel average is then the headline's step_ms_device minus the launch gaps)")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=1, help="1 = packet kernel (default), 0 = exhaustive loop")
@@ -302,7 +341,7 @@ def main():
         rays_per_shade = 1 + sum((int(l["pcfSamples"]) if int(l["shadowType"]) == 1 else
                                   16 + int(l["pcfSamples"]) if int(l["shadowType"]) == 2 else 0) for l in sc.lights)
         f_alg = r["rays_ref"] * (len(sc.objects) * 25 + 40) + (r["rays_ref"] / rays_per_shade) * len(sc.lights) * 120
-        out["valu_flops_equiv"] = {"TFLOPs_equivalent": round(f_alg / (r["kernel_ms"] * 1e-3) / 1e12, 1),
+        out["valu_flops_equiv"] = {"TFLOPs_equivalent": round(f_alg / (r["step_ms_dev"] * 1e-3) / 1e12, 1),
                                    "peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
                                    "note": "flops of the EXHAUSTIVE traversal (SURVEY.md 8(d)); packet culling skips most of "
                                            "them, so this is work-equivalent throughput, not a utilisation"}

@@ -25,15 +25,20 @@ extern "C" {
 
 #define RT_OBJECT_STRIDE 176 /* sizeof(Object), /root/reference/src/Object.h:13-21 */
 #define RT_LIGHT_STRIDE 96   /* sizeof(Light),  /root/reference/src/Light.h:7-20  */
-#define RT_MAX_OBJECTS 512   /* the exhaustive kernel (variant 0) stages the whole scene: 512 * 160 B = 80 KiB of the CU's 160 KiB LDS */
-#define RT_MAX_LIGHTS 64
+/* The shader's SSBOs are runtime-sized arrays whose lengths come from uniforms (raytracingCs.glsl:65-73); the default kernel
+ * takes any count up to these sanity caps.  The exhaustive cross-check kernel (rt_set_variant 0) stages the whole scene in LDS
+ * and refuses scenes beyond RT_EXHAUSTIVE_MAX_* with RT_ERR_TOO_LARGE at render time. */
+#define RT_MAX_OBJECTS 65536
+#define RT_MAX_LIGHTS 4096
+#define RT_EXHAUSTIVE_MAX_OBJECTS 512   /* 512 * 160 B = 80 KiB of the CU's 160 KiB LDS */
+#define RT_EXHAUSTIVE_MAX_LIGHTS 64
 
 typedef enum rt_status {
     RT_OK = 0,
     RT_ERR_INVALID_ARG = -1,
     RT_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error on create */
     RT_ERR_HIP = -3,         /* a HIP call failed; see rt_last_error */
-    RT_ERR_TOO_LARGE = -4,   /* scene exceeds RT_MAX_OBJECTS / RT_MAX_LIGHTS */
+    RT_ERR_TOO_LARGE = -4,   /* scene exceeds RT_MAX_OBJECTS / RT_MAX_LIGHTS (or RT_EXHAUSTIVE_MAX_* under variant 0) */
     RT_ERR_NO_SURFACES = -5, /* readback before any render */
     RT_ERR_PARSE = -6
 } rt_status;
@@ -152,6 +157,15 @@ int rt_render(rt_context *ctx, const rt_params *p);
 int rt_render_to(rt_context *ctx, const rt_params *p, void *dColor, void *dPosition,
                  void *dNormal, void *hipStream);
 
+/* Same dispatch, but the three surfaces are WHOLE width x height images and every pixel of the rendered window (p->x0.., the
+ * strip mapping) is stored at its image position (row-major, row 0 = bottom).  Several contexts -- one per GPU of a node, each
+ * rendering its interleaved strips -- can thus fill ONE frame in place: on peer-mapped devices the stores of the other GPUs go
+ * straight over xGMI into the frame's memory (rt_mgpu_render below does exactly that).  Pixels outside the image are skipped. */
+int rt_render_into_image(rt_context *ctx, const rt_params *p, void *dColorImage, void *dPositionImage, void *dNormalImage,
+                         void *hipStream);
+/* The context's own hipStream_t (the stream rt_render / rt_set_scene use). */
+int rt_context_stream(rt_context *ctx, void **hipStream);
+
 /* ---- glFinish (PerformanceProfiler.cpp:51). */
 int rt_sync(rt_context *ctx);
 
@@ -202,6 +216,10 @@ int rt_debug_stats_ex(rt_context *ctx, uint64_t out[32]);
  * last feedback-scheduled rt_render / rt_render_to launch, in raster tile order; synchronises.  Writes up
  * to cap entries, *nTiles / *tilesX describe the tile grid.  Measurement hook, no reference counterpart. */
 int rt_debug_tile_costs(rt_context *ctx, unsigned *out, int cap, int *nTiles, int *tilesX);
+
+/* Cost classes (0 lightest .. 31 heaviest, ratio 2^(1/4)) the tile-order predictor gave the tiles of the last predicted
+ * launch, raster tile order; *nTiles = capacity of the class buffer (>= that launch's tiles).  Measurement hook; synchronises. */
+int rt_debug_predicted_classes(rt_context *ctx, uint8_t *out, int cap, int *nTiles);
 
 /* The lights' SHADOW TABLES of the current scene (built by rt_set_scene for scenes of <= 256 objects; csrc/rt_shadowtab.inc):
  * per light 24 dwords of header -- (kind, base dword, K, NB) (invBinW, binMax, wlo, nmax^2) (pmin, qmin, invCell, cells)
@@ -345,6 +363,30 @@ int rt_wire_unpack(rt_context *ctx, const void *dWire, size_t rankStrideBytes, s
                    const void *dRootColor, const void *dRootPosition, const void *dRootNormal, int rootStrips,
                    void *dColor, void *dPosition, void *dNormal, int width, int height, int stripRows, int stripCount,
                    void *hipStream);
+
+/* ---- one frame on N GPUs of a node from ONE process and ONE host thread -- what the reference's host is
+ *      (/root/reference/src/main.cpp:3-7, ForwardShadingPipeline.cpp:129-271).  One context per entry of deviceIds (entries
+ *      may repeat: N "devices" that are all device 0 run the N-way plan on a one-GPU box); device deviceIds[0] owns the frame.
+ *      rt_mgpu_render splits the frame into interleaved strips of stripRows rows (default 8, rt_mgpu_set_strip_rows), every
+ *      device renders its strips and its kernel stores them straight into the root's full-frame surfaces over xGMI (peer
+ *      access; csrc/rt_mgpu.cpp) -- no gather buffer, no collective.  Asynchronous: the root context's stream (returned by
+ *      rt_mgpu_get_surfaces) is ordered behind every device's stores, so work enqueued on it afterwards sees the whole frame;
+ *      rt_mgpu_sync / rt_mgpu_readback wait for it.  p describes the WHOLE frame (identity window and strip fields).
+ *      rt_mgpu_last_ms: duration of every device's share of the last frame (HIP events on its stream). */
+typedef struct rt_mgpu rt_mgpu;
+int rt_mgpu_create(rt_mgpu **out, const int *deviceIds, int nDevices);
+int rt_mgpu_destroy(rt_mgpu *m);
+int rt_mgpu_device_count(rt_mgpu *m);
+int rt_mgpu_set_scene(rt_mgpu *m, const void *objects, int nObj, const void *lights, int nLt);
+int rt_mgpu_set_noise(rt_mgpu *m, const uint8_t *r8, int w, int h);
+int rt_mgpu_set_skybox(rt_mgpu *m, const uint16_t *rgb16f, int size);
+int rt_mgpu_set_strip_rows(rt_mgpu *m, int stripRows);
+int rt_mgpu_render(rt_mgpu *m, const rt_params *p);
+int rt_mgpu_sync(rt_mgpu *m);
+int rt_mgpu_get_surfaces(rt_mgpu *m, void **dColor, void **dPosition, void **dNormal, void **rootStream);
+int rt_mgpu_readback(rt_mgpu *m, float *gColor, float *gPosition, uint16_t *gNormal);
+int rt_mgpu_last_ms(rt_mgpu *m, float *perDeviceMs, int cap);
+const char *rt_mgpu_last_error(rt_mgpu *m);
 
 #ifdef __cplusplus
 }

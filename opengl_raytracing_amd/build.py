@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(PKG_DIR, "librt_mi355.so")
 ORACLE_DIR = os.path.join(REPO, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle_rt.so")
 
-SOURCES = ["rt_kernels.hip", "rt_post.hip", "rt_abi.cpp", "rt_host.cpp"]
-HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_packet.inc"), os.path.join(CSRC, "rt_mesa_math.h"), os.path.join(CSRC, "rt_fastmath.h"), os.path.join(REPO, "include", "rt_mi355.h")]
+SOURCES = ["rt_kernels.hip", "rt_post.hip", "rt_abi.cpp", "rt_host.cpp", "rt_mgpu.cpp"]
+HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_packet.inc"), os.path.join(CSRC, "rt_shadowtab.inc"), os.path.join(CSRC, "rt_mesa_math.h"), os.path.join(CSRC, "rt_fastmath.h"), os.path.join(REPO, "include", "rt_mi355.h")]
 
 # -ffp-contract=off: the reference's GL never fuses a*b+c; IEEE divide and
 # sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).

@@ -8,6 +8,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "rt_device.h"
 #include "rt_mesa_math.h"
@@ -58,7 +59,12 @@ struct rt_context {
     // Every stream a render has been issued on (the context's own and the callers'): `last` = its most recent
     // launch (recorded on EVERY launch, feedback or not: rt_set_scene orders the scene rewrite behind all of
     // them), `seenGen` = the tile-order adoption it has already ordered itself behind.
-    struct FbStream { hipStream_t s; hipEvent_t last; unsigned seenGen; };
+    struct FbStream {
+        hipStream_t s; hipEvent_t last; unsigned seenGen;
+        // predicted tile order of the last frame issued on this stream, and the inputs it was predicted from
+        // (class segments: 32 x predCap tile ids; two sets of 32 class sizes, used alternately -- a prediction clears the other set)
+        unsigned *predOrder; unsigned char *predCls; unsigned *predCounts; size_t predCap; unsigned long long predKey; bool predValid; int predSet;
+    };
     static constexpr int kMaxStreams = 8;
     FbStream fbStreams[kMaxStreams] = {};
     int nFbStreams = 0;
@@ -79,7 +85,18 @@ struct rt_context {
     unsigned *dShadowTab = nullptr;
     size_t capShadowTab = 0;
     bool shadowTabValid = false;
-    RtShadowTabGeom stGeomSmall = {32, 64, 24}, stGeomLarge = {16, 32, 24};      // <= 32 objects / more (RT_ST_GEOM overrides both)
+    std::vector<uint8_t> lastScene;            // the bytes of the current scene (objects, then lights): an identical re-upload is a no-op
+    RtShadowTabGeom stGeomSmall = {48, 96, 32}, stGeomLarge = {32, 64, 32};      // <= 32 objects / more (RT_ST_GEOM overrides both); measured: DESIGN.md
+    // Scheduler (packet kernel).  schedMode 2 (default): tiles run longest-first by their MEASURED cost over the last frames of the
+    // same window geometry (the feedback of rounds 1-2); while no measured order exists yet, frames of >= predMinTiles tiles run in
+    // the heavy-first order PREDICTED from their own inputs (rt_predict_tiles_kernel, in the frame's own stream, buffers per stream
+    // in FbStream).  1: measured costs only.  0: raster order.
+    int schedMode = 2;
+    int predMinTiles = 49152;                  // frames of at least this many tiles get a predicted order while no measured one exists (RT_PRED_MIN_TILES)
+    unsigned sceneGen = 0, texGen = 0;         // bumped by rt_set_scene / rt_set_noise / rt_set_skybox / rt_equirect_to_cubemap
+    bool dbgWantCls = false;                   // RT_DEBUG_PRED_CLASSES=1: predictions also store each tile's class
+    const unsigned char *dbgPredCls = nullptr; // class buffer of the last predicted launch (rt_debug_predicted_classes)
+    int dbgPredTiles = 0;
     bool feedback = true;
     unsigned fbPeriod = 32;                    // re-sort period in frames (RT_FB_PERIOD overrides, for measurements)
     std::string err;
@@ -206,6 +223,7 @@ int stream_record(rt_context *c, hipStream_t s, rt_context::FbStream **out) {
     }
     rt_context::FbStream *m = &c->fbStreams[c->nFbStreams++];
     m->s = s;
+    m->predValid = false;
     m->seenGen = 0;                // adoptGen starts at 1 with the first adoption: a new stream always orders itself
     if (!m->last) {
         hipError_t e = hipEventCreateWithFlags(&m->last, hipEventDisableTiming);
@@ -227,9 +245,10 @@ hipError_t fb_wait_others(rt_context *c, const rt_context::FbStream *mine, hipSt
 }
 
 int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint2 *dNormal,
-           unsigned long long *counter, hipStream_t s, bool timed, int countMode = 1) {
+           unsigned long long *counter, hipStream_t s, bool timed, int countMode = 1, bool imageStores = false) {
     RtFrame f;
     build_frame(c, p, &f);
+    f.imageStores = imageStores ? 1 : 0;
     RtDeviceScene sc;
     sc.compiled = c->dCompiled;
     sc.noise = c->dNoise;
@@ -238,6 +257,8 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
     sc.tileCost = nullptr;
     sc.shadowTab = c->shadowTabValid ? c->dShadowTab : nullptr;
     if (!c->dCompiled) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene has not been called");
+    if (c->variant != 1 && (c->nObj > RT_EXHAUSTIVE_MAX_OBJECTS || c->nLt > RT_EXHAUSTIVE_MAX_LIGHTS))
+        return fail(c, RT_ERR_TOO_LARGE, "the exhaustive cross-check kernel stages the scene in LDS: at most 512 objects / 64 lights (use the default kernel)");
     // Longest-first tile order from the previous frames' measured tile costs (same window geometry, any
     // stream).  The first frame of a geometry runs in raster order and only records costs.
     bool sortAfter = false;
@@ -247,7 +268,8 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         const int rc = stream_record(c, s, &mine);
         if (rc) return rc;
     }
-    if (c->variant == 1 && c->feedback && !counter && p->regionW > 0 && p->regionH > 0) {
+    const bool sched = c->variant == 1 && c->schedMode != 0 && c->feedback && !counter && p->regionW > 0 && p->regionH > 0;
+    if (sched) {
         rt_packet_geometry(c->nObj, p->regionW, p->regionH, &bt, &tile, &tilesX, &nTiles);
         if ((size_t)nTiles > c->capTiles) {
             HIP_TRY(c, fb_sync_all(c));
@@ -264,6 +286,15 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             HIP_TRY(c, hipMalloc((void **)&c->dTileOrder[0], (size_t)nTiles * sizeof(unsigned)));
             HIP_TRY(c, hipMalloc((void **)&c->dTileOrder[1], (size_t)nTiles * sizeof(unsigned)));
             c->capTiles = (size_t)nTiles;
+        }
+        // the inputs this frame's tile costs are a function of
+        unsigned long long key = 1469598103934665603ull;
+        {
+            const unsigned char *fb = (const unsigned char *)&f;
+            for (size_t k = 0; k < sizeof f; k++) key = (key ^ fb[k]) * 1099511628211ull;
+            const unsigned gens[3] = {c->sceneGen, c->texGen, (unsigned)c->variant};
+            const unsigned char *gb = (const unsigned char *)gens;
+            for (size_t k = 0; k < sizeof gens; k++) key = (key ^ gb[k]) * 1099511628211ull;
         }
         const bool same = c->fbTiles == nTiles && c->fbTilesX == tilesX && c->fbBt == bt;
         if (!same) {
@@ -305,6 +336,38 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         sc.tileOrder = c->fbCur >= 0 ? c->dTileOrder[c->fbCur] : nullptr;
         sc.tileCost = c->dTileCost;
         sortAfter = true;
+        // No measured order yet (the first frames of a geometry): the order PREDICTED from the frame's own inputs, made in this stream
+        // just before the frame (cached per stream and inputs).  Only for frames large enough that the pass (one path per tile against
+        // every object, 36 us at 1080p / 18 objects) costs less than the order gains: measured it pays from 4K on
+        // (C4: 6.97 -> 6.61 ms), at 1080p the raster order of the configs' scenes is already close to heavy-first and it does not.
+        const double work = (double)nTiles * (double)(p->maxRayDepth > 0 ? p->maxRayDepth : 1) * (double)(c->nObj > 0 ? c->nObj : 1);
+        if (c->fbCur < 0 && c->schedMode == 2 && nTiles >= c->predMinTiles && c->nObj <= RT_ST_MAX_OBJECTS && work <= 3.0e8) {
+            if ((size_t)nTiles > mine->predCap) {
+                HIP_TRY(c, hipStreamSynchronize(s));
+                if (mine->predOrder) HIP_TRY(c, hipFree(mine->predOrder));
+                if (mine->predCls) HIP_TRY(c, hipFree(mine->predCls));
+                mine->predOrder = nullptr; mine->predCls = nullptr; mine->predCap = 0; mine->predValid = false;
+                HIP_TRY(c, hipMalloc((void **)&mine->predOrder, (size_t)33 * nTiles * sizeof(unsigned)));      // the order, then the 32 class segments
+                HIP_TRY(c, hipMalloc((void **)&mine->predCls, (size_t)nTiles));
+                if (!mine->predCounts) {
+                    HIP_TRY(c, hipMalloc((void **)&mine->predCounts, 64 * sizeof(unsigned)));
+                    HIP_TRY(c, hipMemsetAsync(mine->predCounts, 0, 64 * sizeof(unsigned), s));
+                    mine->predSet = 1;
+                }
+                mine->predCap = (size_t)nTiles;
+            }
+            if (!mine->predValid || mine->predKey != key) {
+                mine->predSet ^= 1;
+                HIP_TRY(c, rt_launch_predict_order(f, sc, tilesX, nTiles, mine->predOrder + mine->predCap, (int)mine->predCap,
+                                                   mine->predCounts + 32 * mine->predSet, mine->predCounts + 32 * (mine->predSet ^ 1),
+                                                   c->dbgWantCls ? mine->predCls : nullptr, mine->predOrder, s));
+                mine->predKey = key;
+                mine->predValid = true;
+            }
+            sc.tileOrder = mine->predOrder;
+            c->dbgPredCls = mine->predCls;
+            c->dbgPredTiles = nTiles;
+        }
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->evStart, s));
     HIP_TRY(c, rt_launch_render(f, sc, dColor, dPos, dNormal, counter, c->variant, s, countMode));
@@ -355,6 +418,8 @@ int rt_create(rt_context **out, int deviceId) {
         const int v = atoi(e);
         if (v >= 1 && v <= 1024) c->fbPeriod = (unsigned)v;
     }
+    if (const char *e = getenv("RT_DEBUG_PRED_CLASSES")) c->dbgWantCls = atoi(e) != 0;
+    if (const char *e = getenv("RT_PRED_MIN_TILES")) c->predMinTiles = atoi(e);
     if (const char *e = getenv("RT_ST_GEOM")) {        // "Kcube,Kplan,NB": measurement override of the shadow-table geometry
         int kc = 0, kp = 0, nb = 0;
         if (sscanf(e, "%d,%d,%d", &kc, &kp, &nb) == 3 && kc >= 4 && kc <= 128 && kp >= 4 && kp <= 256 && nb >= 1 && nb <= 128)
@@ -375,11 +440,14 @@ int rt_destroy(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < rt_context::kMaxStreams; i++)
+    for (int i = 0; i < rt_context::kMaxStreams; i++) {
         if (c->fbStreams[i].last) {
             (void)hipEventSynchronize(c->fbStreams[i].last);
             (void)hipEventDestroy(c->fbStreams[i].last);
         }
+        for (void *b : {(void *)c->fbStreams[i].predOrder, (void *)c->fbStreams[i].predCls, (void *)c->fbStreams[i].predCounts})
+            if (b) (void)hipFree(b);
+    }
     void *bufs[] = {c->dShadowTab, c->dObjects, c->dLights, c->dCompiled, c->dNoise, c->dSky, c->dColor, c->dPos, c->dNormal, c->dRayCounter,
                     c->dTileCost, c->dTileSnap, c->dTileOrder[0], c->dTileOrder[1], c->dBloom[0], c->dBloom[1], c->dSsaoDepth, c->dFrameAO[0], c->dFrameAO[1], c->dHistory[0], c->dHistory[1], c->dFrameDisplay};
     for (void *b : bufs)
@@ -404,6 +472,17 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
         return fail(c, RT_ERR_INVALID_ARG, "bad scene arguments");
     if (nObj > RT_MAX_OBJECTS || nLt > RT_MAX_LIGHTS) return fail(c, RT_ERR_TOO_LARGE, "scene exceeds RT_MAX_OBJECTS/RT_MAX_LIGHTS");
     HIP_TRY(c, hipSetDevice(c->device));
+    // The reference re-specifies both SSBOs every frame whether or not anything moved (ImGUIManager.cpp:202, :338).  Identical
+    // bytes leave the device scene, its compiled form and its shadow tables as they are (and the scheduler's view of "the same
+    // frame as before" intact).
+    {
+        const size_t ob = (size_t)nObj * RT_OBJECT_STRIDE, lb = (size_t)nLt * RT_LIGHT_STRIDE;
+        if (c->dCompiled && c->nObj == nObj && c->nLt == nLt && c->lastScene.size() == ob + lb &&
+            (ob == 0 || memcmp(c->lastScene.data(), objects, ob) == 0) && (lb == 0 || memcmp(c->lastScene.data() + ob, lights, lb) == 0))
+            return RT_OK;
+        c->lastScene.clear();              // (refilled at the end: a failed update must not look like the current scene)
+        c->sceneGen++;
+    }
     int rc;
     if ((rc = ensure(c, &c->dObjects, &c->capObjects, (size_t)nObj * RT_OBJECT_STRIDE))) return rc;
     if ((rc = ensure(c, &c->dLights, &c->capLights, (size_t)nLt * RT_LIGHT_STRIDE))) return rc;
@@ -434,13 +513,20 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     HIP_TRY(c, rt_launch_compile_scene(c->dObjects, nObj, c->dLights, nLt, c->dCompiled, c->stream));
     // the lights' shadow tables of this scene (light-space candidate masks, rt_shadowtab.inc)
     c->shadowTabValid = false;
-    if (nObj > 0 && nLt > 0 && nObj <= RT_ST_MAX_OBJECTS) {
+    if (nObj > 0 && nLt > 0 && nObj <= RT_ST_MAX_OBJECTS && nLt <= RT_ST_MAX_LIGHTS) {
         const RtShadowTabGeom &g = nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
         if ((rc = ensure(c, &c->dShadowTab, &c->capShadowTab, rt_shadowtab_dwords(g, nObj, nLt)))) return rc;
         HIP_TRY(c, rt_launch_shadow_tables(c->dCompiled, nObj, nLt, c->dShadowTab, g, c->stream));
         c->shadowTabValid = true;
     }
     HIP_TRY(c, hipEventRecord(c->evScene, c->stream));   // foreign streams order behind this (rt_render_to)
+    try {
+        c->lastScene.resize(objBytes + ltBytes);
+        if (objBytes) memcpy(c->lastScene.data(), objects, objBytes);
+        if (ltBytes) memcpy(c->lastScene.data() + objBytes, lights, ltBytes);
+    } catch (...) {
+        c->lastScene.clear();
+    }
     c->nObj = nObj;
     c->nLt = nLt;
     c->anyPcss = false;
@@ -455,7 +541,8 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
 int rt_set_noise(rt_context *c, const uint8_t *r8, int w, int h) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, fb_sync_all(c));            // frames on every stream read the texture
+    c->texGen++;
     if (c->dNoise) { HIP_TRY(c, hipFree(c->dNoise)); c->dNoise = nullptr; }
     c->noiseW = c->noiseH = 0;
     if (!r8) return RT_OK;
@@ -470,7 +557,8 @@ int rt_set_noise(rt_context *c, const uint8_t *r8, int w, int h) {
 int rt_set_skybox(rt_context *c, const uint16_t *rgb16f, int size) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, fb_sync_all(c));
+    c->texGen++;
     if (c->dSky) { HIP_TRY(c, hipFree(c->dSky)); c->dSky = nullptr; }
     c->skySize = 0;
     if (!rgb16f) return RT_OK;
@@ -516,6 +604,23 @@ int rt_render_to(rt_context *c, const rt_params *p, void *dColor, void *dPositio
     hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
     if (s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->evScene, 0));
     return launch(c, p, (float4 *)dColor, (float4 *)dPosition, (uint2 *)dNormal, nullptr, s, true);
+}
+
+int rt_render_into_image(rt_context *c, const rt_params *p, void *dColorImage, void *dPositionImage, void *dNormalImage, void *hipStream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    int rc = validate_params(c, p);
+    if (rc) return rc;
+    if (!dColorImage || !dPositionImage || !dNormalImage) return fail(c, RT_ERR_INVALID_ARG, "NULL device surface");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    if (s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->evScene, 0));
+    return launch(c, p, (float4 *)dColorImage, (float4 *)dPositionImage, (uint2 *)dNormalImage, nullptr, s, true, 1, true);
+}
+
+int rt_context_stream(rt_context *c, void **hipStream) {
+    if (!c || !hipStream) return RT_ERR_INVALID_ARG;
+    *hipStream = (void *)c->stream;
+    return RT_OK;
 }
 
 int rt_sync(rt_context *c) {
@@ -591,9 +696,11 @@ static int count_rays_impl(rt_context *c, const rt_params *p, uint64_t *rays, in
 
 int rt_set_variant(rt_context *c, int variant) {
     if (!c) return RT_ERR_INVALID_ARG;
-    // bit 8 (0x100) switches the cost-feedback tile order off (raster order every frame)
+    // bit 8 (0x100): raster tile order every frame; bit 9 (0x200): the measured-cost feedback order of rounds 1-2 instead of the
+    // predicted one (default)
     c->variant = variant & 0xff;
     c->feedback = (variant & 0x100) == 0;
+    c->schedMode = (variant & 0x100) ? 0 : ((variant & 0x200) ? 1 : 2);
     c->fbTiles = 0;
     return RT_OK;
 }
@@ -624,6 +731,18 @@ int rt_debug_shadow_tables(rt_context *c, uint32_t *out, size_t capDwords, size_
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out, c->dShadowTab, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_debug_predicted_classes(rt_context *c, uint8_t *out, int cap, int *nTiles) {
+    if (!c || !out || cap < 0 || !nTiles) return RT_ERR_INVALID_ARG;
+    *nTiles = 0;
+    if (!c->dbgPredCls) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, fb_sync_all(c));
+    *nTiles = c->dbgPredTiles;
+    const int n = *nTiles < cap ? *nTiles : cap;
+    HIP_TRY(c, hipMemcpy(out, c->dbgPredCls, (size_t)n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -710,6 +829,7 @@ int rt_equirect_to_cubemap(rt_context *c, const float *hEquirectRGB, int width, 
         return fail(c, RT_ERR_HIP, "rt_equirect_to_cubemap", e);
     }
     if (install) {
+        c->texGen++;
         if (c->dSky) (void)hipFree(c->dSky);
         c->dSky = (decltype(c->dSky))dFaces;
         c->skySize = size;

@@ -20,6 +20,8 @@ struct RtFrame {
     int32_t nObj, nLt;
     int32_t noiseW, noiseH, skySize;
     int32_t anyPcss;                    // some light has shadowType 2: kernel instantiation with paired blocker rays
+    int32_t imageStores;                // 1: the surfaces are whole width x height images, a pixel goes to (image row, image column)
+                                        // (rt_render_into_image: strips of several devices land in one frame); 0: regionW x regionH window
     float sx, sy;                       // (aspect*tanFov)*focalLength, tanFov*focalLength
     // cosineWeightedHemisphere's local direction for the bounce at each depth
     // (identical for every pixel: hammersley(depth*64+frameCount, 64))
@@ -43,6 +45,7 @@ struct RtDeviceScene {
 
 #define RT_ST_HDR_F4 6            // float4 per light header
 #define RT_ST_MAX_OBJECTS 256     // 8 dwords per cell
+#define RT_ST_MAX_LIGHTS 64       // (a table is 0.4-6 MB per light)
 // dwords per cell for a scene of nObj objects (the packet kernel's profiles are compiled for exactly these: rt_packet.inc)
 static inline int rt_shadowtab_words(int nObj) { return nObj <= 32 ? 1 : (nObj <= 64 ? 2 : 8); }
 // Table geometry: cube-map cells per face edge (point / area lights), grid cells per axis (directional), bins; and the
@@ -71,6 +74,9 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
 // Tile geometry of the packet kernel for a given scene size / window (so the ABI layer can size the
 // feedback buffers): workgroup threads, tile edge, tiles per row, total tiles.
 void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, int *tilesX, int *nTiles);
+// Heavy-first tile order predicted from the frame's own inputs (rt_predict_tiles_kernel): no history involved.
+hipError_t rt_launch_predict_order(const RtFrame &f, const RtDeviceScene &sc, int tilesX, int nTiles, unsigned *dSeg, int segStride,
+                                   unsigned *dCursors, unsigned *dNextCursors, unsigned char *dCls, unsigned *dOrder, hipStream_t s);
 hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s);
 hipError_t rt_launch_iota(unsigned *dOrder, int n, hipStream_t s);      // dOrder[i] = i (identity tile order)
 hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,

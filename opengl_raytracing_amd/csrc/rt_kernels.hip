@@ -579,11 +579,13 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
     const int gxI = f.p.x0 + i;
     const int ly = f.p.y0 + j;
     const int gyI = (ly / f.p.stripRows) * f.p.stripCycleRows + f.p.stripOffsetRows + ly % f.p.stripRows;
-    const size_t outIdx = (size_t)j * f.p.regionW + i;
+    const size_t outIdx = f.imageStores ? (size_t)gyI * f.p.width + gxI : (size_t)j * f.p.regionW + i;
     if (gxI >= f.p.width || gyI >= f.p.height) {   // outside the image: GL discards the imageStore
-        gColor[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        gPosition[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        gNormal[outIdx] = make_uint2(0u, 0u);
+        if (!f.imageStores) {                      // (a whole-image surface has no such pixel)
+            gColor[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            gPosition[outIdx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            gNormal[outIdx] = make_uint2(0u, 0u);
+        }
     } else {
     const unsigned gx = (unsigned)gxI, gy = (unsigned)gyI;
 
@@ -745,11 +747,11 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
 #ifndef RT_FB_ACCUM
 #define RT_FB_ACCUM 1
 #endif
-        // costs accumulate between two sorts (a one-wave tile has a single writer per frame, so a plain add does):
-        // the order then follows the tiles' average cost over the last period, which is what predicts the next
+        // costs accumulate between two sorts: the order then follows the tiles' average cost over the last period, which is what predicts the next
         // frames when frameCount rotates the shared bounce sample from frame to frame
-        if (BT == 64) dsc.tileCost[tile] = RT_FB_ACCUM ? dsc.tileCost[tile] + c : c;
-        else atomicAdd(&dsc.tileCost[tile], c);
+        // (atomic: frames in flight on several streams may add to the same tile at once -- ADVICE r2)
+        if (RT_FB_ACCUM) atomicAdd(&dsc.tileCost[tile], c);
+        else dsc.tileCost[tile] = c;
     }
 
     if (COUNT) {
@@ -759,6 +761,151 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
         atomicAdd(blockRays, (unsigned long long)rays);
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(rayCounter, *blockRays);
+    }
+}
+
+// =========================================================================================
+// Tile-cost PREDICTOR: the heavy-first workgroup order of a frame from that frame's own inputs.
+// =========================================================================================
+// A frame is a bag of one-wave tiles whose costs differ by an order of magnitude (a wall tile ends after one bounce, a tile on
+// a glass sphere above the floor runs every bounce, light and sample), and a tile that starts late ends late: in raster order
+// the frame takes 30 % longer than with the heavy tiles first.  Rounds 1-2 ordered the tiles by their MEASURED cost of the
+// previous frames, which only helps while consecutive frames are the same.  This kernel needs no history: one lane per tile
+// follows the path of the tile's centre pixel -- closest hits by the exact tests, the reference's bounce rule (:552-576), no
+// shadow rays, no roulette -- and prices it: per bounce the traversal, per light the set-up and BRDF, per shadow ray its set-up
+// plus one candidate test for every object the light's shadow table lists for that shading point (rt_shadowtab.inc: the very
+// objects the render kernel will visit), 16 blocker rays for a PCSS light, 4 probes on a subsurface material.  The costs go
+// into 32 geometric classes (ratio 2^(1/4)); rt_scatter_tiles_kernel writes the tiles class by class, heaviest first.
+// Scheduling only: no pixel depends on the order (the tests run raster, predicted and measured orders against the oracle).
+// One lane per tile (its centre pixel), one kernel: a lane appends its tile to its class's segment (seg[class][...], one
+// wave-aggregated atomic per class present in the wave), and the render kernel maps its workgroup id to (class, rank) from
+// the 32 class sizes -- no counting pass, no sort.  cursors = this launch's 32 class sizes (zero on entry), nextCursors =
+// the other set, cleared here for the next prediction on this stream.  Candidate tests per shadow ray are priced with a
+// scene-wide constant (a table gather per light and bounce would double the pass's latency for little extra order).
+__global__ __launch_bounds__(64) void rt_predict_tiles_kernel(const RtFrame f, const RtDeviceScene dsc, int tilesX, int nTiles,
+                                                               unsigned *__restrict__ seg, int segStride, unsigned *__restrict__ cursors,
+                                                               unsigned *__restrict__ nextCursors, unsigned char *__restrict__ cls) {
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x * 64 + lane;        // (consecutive lanes = consecutive tiles of a row: inside a class the tiles stay in
+    const bool valid = tile < nTiles;               //  raster order -- a strided walk over the image measured 7-19 % SLOWER, neighbours share cache lines)
+    if (blockIdx.x == 0 && lane < 32) nextCursors[lane] = 0u;
+    // the objects' hot records in LDS (broadcast reads pipeline; dependent scalar loads at two waves per SIMD do not: 36 -> 10 us)
+    extern __shared__ float4 lds[];
+    for (int k = lane; k < f.nObj * RT_HOT_F4; k += 64) lds[k] = dsc.compiled[k];
+    __syncthreads();
+    SceneLds sc;
+    sc.hot = lds;
+    sc.mat = dsc.compiled + f.nObj * RT_HOT_F4;
+    sc.lgt = sc.mat + f.nObj * RT_MAT_F4;
+    sc.global = dsc.compiled;
+    sc.compact = true;
+    sc.matF4Base = f.nObj * RT_HOT_F4;
+    sc.lgtF4Base = f.nObj * (RT_HOT_F4 + RT_MAT_F4);
+    const int tx = valid ? tile % tilesX : 0, ty = valid ? tile / tilesX : 0;
+    const int i = min(tx * 8 + 4, f.p.regionW - 1), j = min(ty * 8 + 4, f.p.regionH - 1);
+    const int gxI = f.p.x0 + i, ly = f.p.y0 + j;
+    const int gyI = (ly / f.p.stripRows) * f.p.stripCycleRows + f.p.stripOffsetRows + ly % f.p.stripRows;
+    float cost = 300.0f;                 // ray generation, stores
+    bool alive = valid && gxI < f.p.width && gyI < f.p.height;
+    const float nz = alive ? sample_noise(f, dsc.noise, (unsigned)gxI, (unsigned)gyI) : 0.0f;
+    Ray ray;
+    {
+        float ux = (((float)gxI + 0.5f) + (nz * 2.0f - 1.0f)) / (float)f.p.width, uy = (((float)gyI + 0.5f) - 1.0f) / (float)f.p.height;
+        ux = (ux * 2.0f - 1.0f) * f.sx;
+        uy = (uy * 2.0f - 1.0f) * f.sy;
+        const v3 cd = V3(f.p.camDir[0], f.p.camDir[1], f.p.camDir[2]), cr = V3(f.p.camRight[0], f.p.camRight[1], f.p.camRight[2]),
+                 cu = V3(f.p.camUp[0], f.p.camUp[1], f.p.camUp[2]);
+        ray.o = V3(f.p.camPos[0], f.p.camPos[1], f.p.camPos[2]);
+        ray.d = normalize((cd + cr * ux) + cu * uy);
+    }
+    const float travCost = 250.0f + 12.0f * (float)min(f.nObj, 64) + 2.0f * (float)f.nObj;      // one packet traversal (masks + a few candidates)
+    const float cand = 1.5f + (float)f.nObj * (1.0f / 28.0f);                                     // objects a shading point's table cell lists, typically
+    for (int depth = 0; depth < f.p.maxRayDepth; ++depth) {
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+        // closest hit: every object, the exact tests
+        float t = f.p.maxRayDistance;
+        int idx = -1;
+        {
+            v3 inv;
+            inv.x = __builtin_amdgcn_rcpf(ray.d.x); inv.y = __builtin_amdgcn_rcpf(ray.d.y); inv.z = __builtin_amdgcn_rcpf(ray.d.z);
+            const float a = dot(ray.d, ray.d);
+            for (int k = 0; k < f.nObj; k++) {
+                const float4 *h = lds + k * RT_HOT_F4;
+                const float4 h0 = h[0], h1 = h[1];
+                if (alive && aabb_test(ray, inv, h0, h1, f.p.maxRayDistance)) {
+                    float tt;
+                    if (shape_test(ray, a, h, __float_as_int(h0.w), tt) && tt > 0.0f && tt < t) { t = tt; idx = k; }
+                }
+            }
+        }
+        if (alive) cost += travCost;
+        alive = alive && idx >= 0;
+        const int ii = alive ? idx : 0;
+        const float4 hb = lds[ii * RT_HOT_F4], h2 = lds[ii * RT_HOT_F4 + 2], h3 = lds[ii * RT_HOT_F4 + 3];
+        const float4 m1 = pk_lane_mat(sc, ii, 1), m2 = pk_lane_mat(sc, ii, 2);
+        const v3 P = ray.o + ray.d * t;
+        const v3 N = (__float_as_int(hb.w) == 0) ? normalize(P - V3(h2)) : V3(h3);
+        if (alive) cost += 350.0f;       // hit set-up, parking, next direction
+        for (int li = 0; li < f.nLt; li++) {
+            const int lb4 = sc.lgtF4Base + li * RT_LGT_F4;
+            const float4 l0 = uni_load4(sc, lb4), l1 = uni_load4(sc, lb4 + 1), l3 = uni_load4(sc, lb4 + 3);
+            const int ltype = __float_as_int(l0.w), shadowType = __float_as_int(l3.x), pcf = max(__float_as_int(l3.y), 0);
+            v3 lightDir = V3(l1);
+            bool lit = alive;
+            if (ltype != 1) {
+                lightDir = V3(l0) - P;
+                lightDir = lightDir * __builtin_amdgcn_rsqf(dot(lightDir, lightDir));
+                if (ltype == 2) lit = lit && dot(lightDir, V3(l1)) > 0.0f;
+            }
+            lit = lit && dot(N, lightDir) > 0.0f;
+            if (alive) cost += 330.0f;   // light set-up + computePBR
+            if (lit && (shadowType == 1 || shadowType == 2)) {
+                cost += 120.0f + (float)min(pcf, 64) * (50.0f + 70.0f * cand);
+                if (shadowType == 2) cost += 16.0f * (60.0f + 25.0f * (float)min(f.nObj, 32));
+            }
+        }
+        if (alive && m2.w > 0.0f) cost += 4.0f * (travCost + 60.0f);
+        if (depth + 1 >= f.p.maxRayDepth) break;
+        if (alive) {
+            const v3 O = P + N * 0.001f;
+            if (m1.y > 0.0f) {
+                const int dd = depth < RT_MAX_DEPTH ? depth : RT_MAX_DEPTH - 1;
+                ray.d = normalize(mix_fast(reflect(ray.d, N), hemisphere_dir(V3(f.hemi[dd][0], f.hemi[dd][1], f.hemi[dd][2]), N), m1.x));
+                ray.o = O;
+            } else if (m1.w > 0.0f) {
+                ray.d = calc_refraction(ray, N, m1.z);
+                ray.o = P - N * 0.001f;
+            } else {
+                ray.d = reflect(ray.d, N);
+                ray.o = O;
+            }
+        }
+    }
+    // 32 geometric classes, ratio 2^(1/4), from 2^8 = 256 units; NaN / inf -> top class
+    cost = (cost == cost) ? fminf(cost, 3.0e38f) : 3.0e38f;
+    int c = (int)(4.0f * __log2f(fmaxf(cost, 1.0f))) - 32;
+    c = min(max(c, 0), 31);
+    // a tile next to a heavier one is probably cut by the same silhouette: pull it up to one class below its row neighbours
+    {
+        const int cl = __shfl_up(c, 1), cr2 = __shfl_down(c, 1);
+        const int nb = max((lane & 63) > 0 ? cl : 0, (lane & 63) < 63 ? cr2 : 0);
+        c = max(c, nb - 1);
+    }
+    if (valid && cls) cls[tile] = (unsigned char)c;
+    unsigned long long rem = __builtin_amdgcn_ballot_w64(valid);
+    while (rem) {                        // one atomic per class present in the wave
+        const int c0 = __builtin_amdgcn_readlane(c, __builtin_ctzll(rem));
+        const bool sel = valid && c == c0;
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(sel);
+        const int first = __builtin_ctzll(mm);
+        unsigned base = 0;
+        if (lane == first) base = atomicAdd(&cursors[c0], (unsigned)__builtin_popcountll(mm));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
+        if (sel) {
+            const unsigned pos = base + (unsigned)__builtin_popcountll(mm & ((1ull << lane) - 1ull));
+            if (pos < (unsigned)segStride) seg[(size_t)c0 * segStride + pos] = (unsigned)tile;
+        }
+        rem &= ~mm;
     }
 }
 
@@ -851,9 +998,9 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 #define RT_ST_NMAX 8.0f         // lanes whose shading normal is longer take every object (the tables' aim-error bound assumes |N| <= this)
 #endif
 hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s) {
-    if (nLt <= 0 || nObj <= 0 || nObj > RT_ST_MAX_OBJECTS) return hipSuccess;
+    if (nLt <= 0 || nObj <= 0 || nObj > RT_ST_MAX_OBJECTS || nLt > RT_ST_MAX_LIGHTS) return hipSuccess;
     const int NW = rt_shadowtab_words(nObj);
-    hipLaunchKernelGGL(rt_shadowtab_headers_kernel, dim3(1), dim3(RT_MAX_LIGHTS), 0, s, dCompiled, nObj, nLt, (float4 *)dTab, g.Kcube, g.Kplan,
+    hipLaunchKernelGGL(rt_shadowtab_headers_kernel, dim3(1), dim3(64), 0, s, dCompiled, nObj, nLt, (float4 *)dTab, g.Kcube, g.Kplan,
                        g.NB, NW, RT_ST_NMAX);
     const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
     const size_t maxCells = cube > plan ? cube : plan;
@@ -868,12 +1015,13 @@ hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, u
 hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *dColor, float4 *dPos,
                             uint2 *dNormal, unsigned long long *dRayCounter, int variant, hipStream_t s, int countMode) {
     if (f.p.regionW <= 0 || f.p.regionH <= 0) return hipSuccess;
+    if (variant != 1 && (f.nObj > RT_EXHAUSTIVE_MAX_OBJECTS || f.nLt > RT_EXHAUSTIVE_MAX_LIGHTS)) return hipErrorInvalidValue;      // (the ABI refuses first)
     const size_t sceneBytes = (rt_compiled_f4(f.nObj, f.nLt) + 1) * sizeof(float4);   // exhaustive kernel: whole scene + 16 B block counter
     if (variant == 1) {
         int bt, tile, tilesX, nTiles;
         rt_packet_geometry(f.nObj, f.p.regionW, f.p.regionH, &bt, &tile, &tilesX, &nTiles);
         dim3 grid(nTiles);
-        const bool light = bt == 64 && f.nObj <= RT_PK_LIGHT_SCENE;
+        const bool light = bt == 64 && f.nObj <= RT_PK_LIGHT_SCENE && !(f.nObj > 0 && f.nLt > 0 && !sc.shadowTab);
         // LDS: the AABBs (2 float4 per object) + the 16-byte counter slot + the profile's parking area
         const size_t ldsBytes = ((size_t)((light || PkHeavy::boundsLds) ? f.nObj * 2 : 0) + 1) * sizeof(float4) +
                                 (size_t)(light ? PkLight::parkFloats : PkHeavy::parkFloats) * bt * sizeof(float);
@@ -883,17 +1031,19 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
             else if (dRayCounter) hipLaunchKernelGGL((rt_render_packet_kernel<1, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);            \
             else hipLaunchKernelGGL((rt_render_packet_kernel<0, BT_, true, PROFILE_>), grid, dim3(BT_), ldsBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);                             \
         } while (0)
-        if (PkLight::tabWords > 0 && !sc.shadowTab && f.nObj > 0 && f.nLt > 0 && f.nObj <= RT_ST_MAX_OBJECTS) return hipErrorInvalidValue;     // (rt_set_scene builds them)
+        // scenes without shadow tables (more than RT_ST_MAX_OBJECTS objects or RT_ST_MAX_LIGHTS lights: rt_set_scene builds none)
+        // run the profile that finds the lights' candidates per packet
+        const bool noTab = PkLight::tabWords > 0 && f.nObj > 0 && f.nLt > 0 && (!sc.shadowTab || f.nObj > RT_ST_MAX_OBJECTS);
         if (f.anyPcss) {
-            if (light) RT_LAUNCH_PK(64, PkLightS);
+            if (noTab) RT_LAUNCH_PK(64, PkHugeS);
+            else if (light) RT_LAUNCH_PK(64, PkLightS);
             else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1S);
-            else if (f.nObj <= RT_ST_MAX_OBJECTS) RT_LAUNCH_PK(64, PkHeavyS);
-            else RT_LAUNCH_PK(64, PkHugeS);
+            else RT_LAUNCH_PK(64, PkHeavyS);
         } else {
-            if (light) RT_LAUNCH_PK(64, PkLight);
+            if (noTab) RT_LAUNCH_PK(64, PkHuge);
+            else if (light) RT_LAUNCH_PK(64, PkLight);
             else if (f.nObj <= 64) RT_LAUNCH_PK(64, PkHeavy1);
-            else if (f.nObj <= RT_ST_MAX_OBJECTS) RT_LAUNCH_PK(64, PkHeavy);
-            else RT_LAUNCH_PK(64, PkHuge);
+            else RT_LAUNCH_PK(64, PkHeavy);
         }
 #undef RT_LAUNCH_PK
     } else {
@@ -903,6 +1053,37 @@ hipError_t rt_launch_render(const RtFrame &f, const RtDeviceScene &sc, float4 *d
         else
             hipLaunchKernelGGL(rt_render_kernel<0>, grid, dim3(BLOCK_THREADS), sceneBytes, s, f, sc, dColor, dPos, dNormal, dRayCounter);
     }
+    return hipGetLastError();
+}
+
+// Predicted heavy-first tile order of frame f into dOrder (nTiles entries).  Scratch: dSeg = 32 x segStride tile ids (the tiles of
+// class c), dCursors = 32 class sizes (zero on entry; dNextCursors is cleared for the next prediction); dCls (may be NULL) = class
+// per tile for diagnostics.
+__global__ __launch_bounds__(256) void rt_compact_order_kernel(const unsigned *__restrict__ seg, int segStride, const unsigned *__restrict__ counts,
+                                                                unsigned *__restrict__ order, int nTiles) {
+    __shared__ unsigned off[33];
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int c = 31; c >= 0; c--) { off[c] = run; run += counts[c]; }      // heaviest class first
+        off[32] = run;
+    }
+    __syncthreads();
+    for (int c = 31; c >= 0; c--) {
+        const unsigned n = counts[c];
+        for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+            const unsigned pos = off[c] + k;
+            if (pos < (unsigned)nTiles) order[pos] = seg[(size_t)c * segStride + k];
+        }
+    }
+}
+
+hipError_t rt_launch_predict_order(const RtFrame &f, const RtDeviceScene &sc, int tilesX, int nTiles, unsigned *dSeg, int segStride,
+                                   unsigned *dCursors, unsigned *dNextCursors, unsigned char *dCls, unsigned *dOrder, hipStream_t s) {
+    if (nTiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_predict_tiles_kernel, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), (size_t)f.nObj * RT_HOT_F4 * sizeof(float4), s, f,
+                       sc, tilesX, nTiles, dSeg, segStride, dCursors, dNextCursors, dCls);
+    // the class segments as one order array (the render kernel reads tileOrder[blockIdx.x] and nothing else)
+    hipLaunchKernelGGL(rt_compact_order_kernel, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, s, dSeg, segStride, dCursors, dOrder, nTiles);
     return hipGetLastError();
 }
 

@@ -34,7 +34,10 @@ EXPORTS = [
     "rt_count_rays", "rt_count_rays_traced", "rt_debug_stats", "rt_debug_stats_ex", "rt_debug_tile_costs", "rt_set_variant", "rt_last_error", "rt_generate_aabb", "rt_camera_vectors",
     "rt_scene_parse", "rt_scene_write", "rt_taa_resolve", "rt_taa_jitter", "rt_bloom", "rt_ssao", "rt_ssao_blur",
     "rt_camera_matrices", "rt_equirect_to_cubemap", "rt_frame", "rt_frame_surfaces", "rt_strip_local_rows", "rt_deinterleave",
-    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack", "rt_debug_mesa_math", "rt_debug_shadow_tables",
+    "rt_wire_bytes", "rt_wire_pack", "rt_wire_unpack", "rt_debug_mesa_math", "rt_debug_shadow_tables", "rt_debug_predicted_classes",
+    "rt_render_into_image", "rt_context_stream", "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_device_count", "rt_mgpu_set_scene", "rt_mgpu_set_noise",
+    "rt_mgpu_set_skybox", "rt_mgpu_set_strip_rows", "rt_mgpu_render", "rt_mgpu_sync", "rt_mgpu_get_surfaces", "rt_mgpu_readback", "rt_mgpu_last_ms",
+    "rt_mgpu_last_error",
 ]
 
 
@@ -69,6 +72,22 @@ def load_library(build_if_missing=True):
             raise RtError(-2, f"{path} not built (run python -m opengl_raytracing_amd.build)")
         _build.build_library()
     lib = ctypes.CDLL(path)
+    if "RT_LIB" in os.environ:          # an experiment build (tools/gpu_try.py) may predate newer entry points: bind what it has
+        class _Lenient:
+            def __init__(self, real):
+                object.__setattr__(self, "_real", real)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._real, name)
+                except AttributeError:
+                    class _Missing:
+                        argtypes = restype = None
+
+                        def __call__(self, *a):
+                            raise RtError(-2, f"{name} is not exported by {path}")
+                    return _Missing()
+        lib = _Lenient(lib)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     P = ctypes.POINTER
     lib.rt_create.argtypes = [P(vp), ci]
@@ -112,8 +131,25 @@ def load_library(build_if_missing=True):
     lib.rt_wire_unpack.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.rt_debug_mesa_math.argtypes = [vp, vp, ci]
     lib.rt_debug_shadow_tables.argtypes = [vp, vp, ctypes.c_size_t, P(ctypes.c_size_t), P(ci)]
+    lib.rt_debug_predicted_classes.argtypes = [vp, vp, ci, P(ci)]
+    lib.rt_render_into_image.argtypes = [vp, P(L.RtParams), vp, vp, vp, vp]
+    lib.rt_context_stream.argtypes = [vp, P(vp)]
+    lib.rt_mgpu_create.argtypes = [P(vp), P(ci), ci]
+    lib.rt_mgpu_destroy.argtypes = [vp]
+    lib.rt_mgpu_device_count.argtypes = [vp]
+    lib.rt_mgpu_set_scene.argtypes = [vp, vp, ci, vp, ci]
+    lib.rt_mgpu_set_noise.argtypes = [vp, vp, ci, ci]
+    lib.rt_mgpu_set_skybox.argtypes = [vp, vp, ci]
+    lib.rt_mgpu_set_strip_rows.argtypes = [vp, ci]
+    lib.rt_mgpu_render.argtypes = [vp, P(L.RtParams)]
+    lib.rt_mgpu_sync.argtypes = [vp]
+    lib.rt_mgpu_get_surfaces.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
+    lib.rt_mgpu_readback.argtypes = [vp, vp, vp, vp]
+    lib.rt_mgpu_last_ms.argtypes = [vp, P(ctypes.c_float), ci]
+    lib.rt_mgpu_last_error.argtypes = [vp]
+    lib.rt_mgpu_last_error.restype = ctypes.c_char_p
     for name in EXPORTS:
-        if name != "rt_last_error":
+        if name not in ("rt_last_error", "rt_mgpu_last_error", "rt_wire_bytes"):
             getattr(lib, name).restype = ci
     _LIB = lib
     return lib
@@ -410,6 +446,13 @@ class RayTracer:
         self._check(self.lib.rt_ssao_blur(self.ctx, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), width, height,
                                           int(bool(horizontal)), ctypes.c_void_p(stream) if stream else None), "rt_ssao_blur")
 
+    def predicted_classes(self, n_tiles):
+        """Cost classes (uint8[n_tiles], raster tile order) of the last predicted launch."""
+        out = np.zeros(n_tiles, dtype=np.uint8)
+        n = ctypes.c_int(0)
+        self._check(self.lib.rt_debug_predicted_classes(self.ctx, _ptr(out), n_tiles, ctypes.byref(n)), "rt_debug_predicted_classes")
+        return out
+
     def shadow_tables(self):
         """(dwords uint32[n], words per cell) of the current scene's shadow tables (headers + cells), or (None, 0)."""
         n, w = ctypes.c_size_t(0), ctypes.c_int(0)
@@ -451,3 +494,73 @@ class RayTracer:
                                             root_strips, ctypes.c_void_p(d_color), ctypes.c_void_p(d_pos),
                                             ctypes.c_void_p(d_normal), width, height, strip_rows, strip_count,
                                             ctypes.c_void_p(stream) if stream else None), "rt_wire_unpack")
+
+
+class MultiGpuRayTracer:
+    """rt_mgpu_*: one frame on N devices from one process; the devices' kernels store their strips straight into device 0's frame
+    (include/rt_mi355.h).  `devices` may repeat an id (the N-way plan on one GPU)."""
+
+    def __init__(self, devices, strip_rows=8):
+        self.lib = load_library()
+        self.m = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        rc = self.lib.rt_mgpu_create(ctypes.byref(self.m), arr, len(devices))
+        if rc:
+            self.m = None
+            raise RtError(rc, "rt_mgpu_create (peer access between the devices?)")
+        self.n = len(devices)
+        self._check(self.lib.rt_mgpu_set_strip_rows(self.m, strip_rows), "rt_mgpu_set_strip_rows")
+        self._size = None
+
+    def _check(self, rc, what):
+        if rc:
+            raise RtError(rc, f"{what}: {self.lib.rt_mgpu_last_error(self.m).decode()}")
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.lib.rt_mgpu_destroy(self.m)
+            self.m = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, scene):
+        objects, lights = np.ascontiguousarray(scene.objects), np.ascontiguousarray(scene.lights)
+        self._check(self.lib.rt_mgpu_set_scene(self.m, _ptr(objects) if len(objects) else None, len(objects),
+                                               _ptr(lights) if len(lights) else None, len(lights)), "rt_mgpu_set_scene")
+        if scene.noise is None:
+            self._check(self.lib.rt_mgpu_set_noise(self.m, None, 0, 0), "rt_mgpu_set_noise")
+        else:
+            r8 = np.ascontiguousarray(scene.noise, dtype=np.uint8)
+            self._check(self.lib.rt_mgpu_set_noise(self.m, _ptr(r8), r8.shape[1], r8.shape[0]), "rt_mgpu_set_noise")
+        faces = np.ascontiguousarray(scene.skybox, dtype=np.float16) if scene.use_skybox else None
+        self._check(self.lib.rt_mgpu_set_skybox(self.m, _ptr(faces), faces.shape[1] if faces is not None else 0), "rt_mgpu_set_skybox")
+
+    def render(self, params):
+        self._check(self.lib.rt_mgpu_render(self.m, ctypes.byref(params)), "rt_mgpu_render")
+        self._size = (params.width, params.height)
+
+    def sync(self):
+        self._check(self.lib.rt_mgpu_sync(self.m), "rt_mgpu_sync")
+
+    def readback(self):
+        w, h = self._size
+        col = np.empty((h, w, 4), dtype=np.float32)
+        pos = np.empty((h, w, 4), dtype=np.float32)
+        nrm = np.empty((h, w, 4), dtype=np.float16)
+        self._check(self.lib.rt_mgpu_readback(self.m, _ptr(col), _ptr(pos), _ptr(nrm)), "rt_mgpu_readback")
+        return col, pos, nrm
+
+    def last_ms(self):
+        out = (ctypes.c_float * self.n)()
+        self._check(self.lib.rt_mgpu_last_ms(self.m, out, self.n), "rt_mgpu_last_ms")
+        return list(out)

@@ -109,5 +109,6 @@ def tracer(host, request):
     (variant 1) and the exhaustive per-lane loop (variant 0)."""
     rt = host.RayTracer(0)
     rt.set_variant(request.param)
+    rt.variant = request.param
     yield rt
     rt.close()

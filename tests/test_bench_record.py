@@ -41,6 +41,10 @@ def test_roofline_record_is_a_fraction_of_the_valu_issue_peak(cfg):
     # a record measured on other sources is flagged
     stale = bench.roofline_record(cfg, sc, n_px, 10 * n_px, kernel_ms, c, "0" * 16)
     assert stale["roofline"]["pmc_matches_this_build"] is False
+    # ... and so is a record that carries no hash at all (it used to count as matching)
+    untied = dict(c)
+    untied["src_hash"] = None
+    assert bench.roofline_record(cfg, sc, n_px, 10 * n_px, kernel_ms, untied, c.get("src_hash") or "x")["roofline"]["pmc_matches_this_build"] is False
 
 
 def test_committed_pmc_records_belong_to_the_committed_kernel_sources():

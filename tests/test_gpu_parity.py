@@ -158,8 +158,9 @@ def test_c5_at_7680x4320_against_reference_fixture(tracer):
         en += compare_surface(nrm.astype(np.float32), g["win8k_normal"][k].astype(np.float32), rtol=0, atol=0)["exact_mask"].sum()
         okc += compare_surface(col, g["win8k_color"][k])["ok_mask"].sum()
     print(f"c5 8K: HIP vs reference: gPosition exact {ep / n_px:.6f} gNormal exact {en / n_px:.6f} gColor 1e-4 {okc / n_px:.6f}")
-    assert ep / n_px >= 0.999 and en / n_px >= 0.999
-    assert okc / n_px >= 0.995
+    # (the gates of the oracle's own comparison with this fixture, tests/test_oracle_golden.py: HIP == oracle bit for bit)
+    assert ep / n_px >= 0.9995 and en / n_px >= 0.9995
+    assert okc / n_px >= 0.999
 
 
 def test_nan_and_ub_corners_match_oracle(tracer, host, oracle):
@@ -193,7 +194,9 @@ def test_edge_sizes_and_empty_scenes(tracer, host, oracle):
 
 
 def test_many_objects_and_limits(tracer, host, oracle):
-    """RT_MAX_OBJECTS (512) records in LDS; one more is refused with RT_ERR_TOO_LARGE."""
+    """The SSBOs are runtime-sized (raytracingCs.glsl:65-73): the default kernel takes any object count (2 048 here, against the
+    oracle); the exhaustive cross-check kernel stages the scene in LDS and refuses more than 512 objects at render time with
+    RT_ERR_TOO_LARGE, leaving the context usable."""
     rng = scenes.SplitMix64(99)
     objs = scenes._spheres(rng, 512)
     objs["radius"] *= 0.4
@@ -202,10 +205,24 @@ def test_many_objects_and_limits(tracer, host, oracle):
     sc = scenes.Scene("max", objs, lights, 64, 48, 2, dict(scenes.CAMERA))
     p = sc.params()
     assert_bit_exact(render_gpu(tracer, sc, p), oracle.render(sc, p), "512 objects")
-    big = scenes._spheres(rng, 513)
-    with pytest.raises(host.RtError) as e:
-        tracer.set_scene(big, lights)
-    assert e.value.code == -4
+    big = scenes._spheres(rng, 2048)
+    big["radius"] *= 0.25
+    host.generate_aabb(big)
+    lights3 = scenes._lights3(L.SHADOW_PCF)
+    scb = scenes.Scene("big", big, lights3, 64, 48, 3, dict(scenes.CAMERA))
+    if tracer.variant == 0:
+        tracer.set_scene(big, lights3)
+        with pytest.raises(host.RtError) as e:
+            tracer.render(scb.params())
+        assert e.value.code == -4
+    else:
+        assert_bit_exact(render_gpu(tracer, scb, scb.params()), oracle.render(scb, scb.params()), "2048 objects")
+        assert tracer.count_rays(scb.params()) == oracle.render(scb, scb.params())[3]
+        many = scenes._lights3(L.SHADOW_PCF)
+        many = scenes._concat([many] * 24)[:70].copy()             # 70 lights: beyond the shadow tables' 64 -> the per-packet light culls
+        many["position"][:, 0] += np.linspace(-4, 4, 70).astype(np.float32)
+        scl = scenes.Scene("lights70", sc.objects[:40].copy(), many, 48, 32, 2, dict(scenes.CAMERA))
+        assert_bit_exact(render_gpu(tracer, scl, scl.params()), oracle.render(scl, scl.params()), "70 lights")
     tracer.set_scene(objs, lights)   # context still usable
     with pytest.raises(host.RtError) as e:
         tracer.render(sc.params(max_ray_depth=33))
@@ -227,11 +244,12 @@ def test_pcf_sample_counts_and_shadow_types(tracer, host, oracle):
         assert_bit_exact(render_gpu(tracer, sc, p), oracle.render(sc, p), f"pcf {samples} type {stype}")
 
 
-@pytest.mark.parametrize("cfg,samples", [(4, 8), (4, 16), (5, 9), (5, 16)])
+@pytest.mark.parametrize("cfg,samples", [(4, 3), (4, 8), (4, 16), (5, 3), (5, 9), (5, 16)])
 def test_many_pcf_samples_in_many_object_scenes(tracer, host, oracle, cfg, samples):
-    """From 8 samples per light on, the many-object kernel profile refines each light's candidate mask per LANE before the
-    sample loops (rt_packet.inc, RT_PK_CONE): C4's / C5's scenes with 8 / 9 / 16 PCF samples, and with a softness near the
-    bound where the jitter interval swallows whole direction components (filterSize 0.15 of the 0.2 limit)."""
+    """From RT_PK_REACH_MIN_SAMPLES = 3 samples per light on, the many-object kernel profiles refine each light's candidate mask
+    per LANE on the spheres themselves before the sample loops (rt_packet.inc, RT_PK_REACH): C4's / C5's scenes at the threshold
+    (3), at 8 / 9 and at the UI's maximum of 16 PCF samples, and with a softness near the bound where the jitter interval swallows
+    whole direction components (filterSize 0.15 of the 0.2 limit)."""
     sc = scenes.make_scene(cfg, host.generate_aabb)
     sc.lights["pcfSamples"] = samples
     p = sc.params(width=80, height=48)
@@ -422,9 +440,9 @@ def _fuzz_scene(seed):
     return sc
 
 
-@pytest.mark.parametrize("block", range(int(os.environ.get("RT_FUZZ_BLOCKS", "4"))))      # 10 seeds per block
+@pytest.mark.parametrize("block", range(int(os.environ.get("RT_FUZZ_BLOCKS", "10"))))      # 10 seeds per block
 def test_fuzzed_scenes_bit_exact_vs_oracle(tracer, host, oracle, block):
-    """40 random scenes per kernel variant (see _fuzz_scene): all three surfaces and the ray count
+    """100 random scenes per kernel variant (see _fuzz_scene): all three surfaces and the ray count
     must equal the oracle's bit for bit -- in particular, packet culling may never drop an object
     some lane's exact intersectAABB would have passed."""
     for seed in range(block * 10, block * 10 + 10):
@@ -552,3 +570,122 @@ def test_scene_updates_between_frames_in_flight_on_three_streams(host, oracle):
         for k in range(n_frames):
             want = variants[k % 4][1]
             assert_bit_exact(tuple(t.cpu().numpy() for t in bufs[k]), want, f"frame {k} (scene {k % 4})")
+
+
+def _grazing_scene(kind, scale, offset, samples, softness, ltype, seed):
+    """Shadow rays that graze: a floor under a light, 40 spheres between them whose shadow limbs cross the view -- every pixel on
+    a shadow's edge is a ray within rounding of a sphere's limb.  kind: 'tiny' (radii 1e-3..1e-2 of the scene's scale), 'mixed',
+    'huge' (one sphere of radius 1e3 scales whose limb cuts the view), 'axis' (centres exactly on the segment shading point ->
+    light of the central pixels, where dot(oc, oc) - p*p cancels).  The whole scene is scaled and moved far from the origin
+    (|coordinates| up to 1e5: the differences the cull levels take cancel there)."""
+    rng = np.random.default_rng(seed)
+    s = np.float32(scale)
+    off = np.array(offset, dtype=np.float32)
+    n = 40
+    objs = L.default_objects(n + 1)
+    objs["type"][:n] = L.SPHERE
+    lightp = np.array([0.3, 8.0, -0.2], dtype=np.float32) * s
+    if kind == "tiny":
+        r = 10.0 ** rng.uniform(-3, -2, n)
+        pos = np.stack([rng.uniform(-2, 2, n), rng.uniform(0.05, 0.5, n), rng.uniform(-2, 2, n)], 1)
+    elif kind == "huge":
+        r = 10.0 ** rng.uniform(-1, 0, n)
+        pos = np.stack([rng.uniform(-3, 3, n), rng.uniform(1, 5, n), rng.uniform(-3, 3, n)], 1)
+        r[0] = 1000.0
+        pos[0] = (1000.6, 3.0, 0.0)                       # its limb passes 0.6 from the light's axis
+    elif kind == "axis":
+        r = 10.0 ** rng.uniform(-2, -0.5, n)
+        tq = rng.uniform(0.1, 0.9, n)
+        q = np.stack([rng.uniform(-2, 2, n), np.zeros(n), rng.uniform(-2, 2, n)], 1)      # floor points
+        pos = q + tq[:, None] * (lightp / s - q)          # centres ON the segments floor point -> light
+    else:
+        r = 10.0 ** rng.uniform(-2.5, 0.3, n)
+        pos = np.stack([rng.uniform(-3, 3, n), rng.uniform(0.2, 6, n), rng.uniform(-3, 3, n)], 1)
+    objs["position"][:n] = (pos * s).astype(np.float32) + off
+    objs["radius"][:n] = (r * s).astype(np.float32)
+    objs["albedo"][:n] = 0.7
+    objs["roughness"][:n] = 0.4
+    objs["type"][n] = L.PLANE                              # the floor the shadows fall on (diffuse: a second bounce of grazing rays)
+    objs["position"][n] = off
+    objs["normal"][n] = (0, 1, 0)
+    objs["size"][n] = (4000 * s, 4000 * s)
+    objs["albedo"][n] = 0.8
+    objs["diffuseStrength"][n] = 0.7
+    from opengl_raytracing_amd import host as H
+    H.generate_aabb(objs)
+    lts = L.default_lights(1)
+    lts["type"] = ltype
+    lts["position"] = lightp + off
+    lts["direction"] = (-0.1, -1.0, 0.05) if ltype == L.DIRECTIONAL else (0.0, 1.0, 0.0)
+    lts["intensity"] = 30.0 * float(s) * float(s) if ltype == L.AREA else 6.0
+    lts["shadowType"] = L.SHADOW_PCF
+    lts["pcfSamples"] = samples
+    lts["shadowSoftness"] = softness
+    cam = dict(cam_pos=tuple((np.array([0.0, 9.0, 0.3], dtype=np.float32) * s + off).tolist()), cam_dir=(0.0, -1.0, 0.0),
+               cam_up=(0.0, 0.0, -1.0), cam_right=(1.0, 0.0, 0.0), fov_deg=40.0)
+    return scenes.Scene(f"graze-{kind}", objs, lts, 96, 64, 2, cam)
+
+
+@pytest.mark.parametrize("kind", ["tiny", "mixed", "huge", "axis"])
+def test_grazing_shadow_rays_far_from_the_origin(tracer, host, oracle, kind):
+    """ADVICE r2 / VERDICT r2 #4b: the per-lane sphere level (RT_PK_REACH) and the shadow tables drop candidates on margin
+    arguments; this aims rays at sphere limbs -- shadow edges of tiny, huge and on-axis spheres, at scales 1 and 1e3 and offsets
+    up to 1e5 from the origin, 3 / 4 / 16 samples, softness 0 to the 0.2 filter bound, point / area / directional lights (41
+    objects: the many-object profile, per-lane level on from 3 samples) -- against the oracle, bit for bit."""
+    k = 0
+    for scale, offset in [(1.0, (0, 0, 0)), (1.0, (1e4, -3e3, 2e4)), (1e3, (0, 0, 0)), (1.0, (1e5, 1e5, -1e5)), (1e-2, (50.0, 0.0, -20.0))]:
+        for samples, softness, ltype in [(3, 1.0, L.POINT), (4, 0.0, L.AREA), (16, 39.0, L.POINT), (4, 1.0, L.DIRECTIONAL), (16, 10.0, L.AREA)]:
+            k += 1
+            if (k + len(kind)) % 2:           # half of the 25 combinations per kind, a different half for each
+                continue
+            sc = _grazing_scene(kind, scale, offset, samples, softness, ltype, seed=k)
+            p = sc.params()
+            gpu = render_gpu(tracer, sc, p)
+            cpu = oracle.render(sc, p)
+            assert_bit_exact(gpu, cpu, f"{kind} scale {scale} offset {offset} samples {samples} softness {softness} light {ltype}")
+            assert tracer.count_rays(p) == cpu[3]
+
+
+@pytest.mark.parametrize("cfg", [3, 4, 5])
+def test_whole_frames_packet_kernel_equals_exhaustive_kernel(host, oracle, cfg):
+    """VERDICT r2 #4a: C3, C4, C5 at their REAL sizes (3840x2160, 7680x4320), whole frame: the packet kernel (shadow tables, packet
+    and per-lane culls, predicted / measured tile order) against the exhaustive kernel (every object for every ray, raster order)
+    -- two independently structured kernels, the second one checked against the oracle on windows of the same frames -- all three
+    surfaces bit for bit on the device, equal ray counts; plus 64 random 32x32 windows of the frame against the oracle."""
+    import torch
+    from opengl_raytracing_amd import dist as D
+    sc = scenes.make_scene(cfg, host.generate_aabb)
+    p = sc.params()
+    W, H = sc.width, sc.height
+    one = D.StripPlan(W, H, H, 1)
+    outs = []
+    rays = []
+    for variant in (1, 0):
+        with host.RayTracer(0) as rt:
+            rt.load(sc)
+            rt.set_variant(variant)
+            buf = D.alloc_rank_buffer(one, "cuda")
+            c, q, n = D.surface_views(buf, one)
+            rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr())
+            if variant == 1:      # a second and third frame: the measured-cost order replaces the predicted one
+                rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr())
+                rt.render_to(p, c.data_ptr(), q.data_ptr(), n.data_ptr())
+            rt.sync()
+            torch.cuda.synchronize()
+            outs.append((c, q, n))
+            rays.append(rt.count_rays(p))
+    assert rays[0] == rays[1]
+    for a, b, name in zip(outs[0], outs[1], ("gColor", "gPosition", "gNormal")):
+        it = torch.int16 if a.dtype == torch.float16 else torch.int32
+        same = torch.equal(a.view(it), b.view(it))
+        if not same:          # NaN payloads may differ: compare as floats with NaN == NaN
+            fa, fb = a.float(), b.float()
+            same = bool((((fa == fb) | (fa.isnan() & fb.isnan()))).all().item())
+        assert same, f"C{cfg} {W}x{H}: {name} of the packet kernel differs from the exhaustive kernel's"
+    rng = np.random.default_rng(100 + cfg)
+    col, pos, nrm = (t.cpu().numpy() for t in outs[0])
+    for _ in range(64):
+        x0, y0 = int(rng.integers(0, W - 32)), int(rng.integers(0, H - 32))
+        oc, op, on, _ = oracle.render(sc, sc.params(window=(x0, y0, 32, 32)))
+        assert_bit_exact((col[y0:y0 + 32, x0:x0 + 32], pos[y0:y0 + 32, x0:x0 + 32], nrm[y0:y0 + 32, x0:x0 + 32]), (oc, op, on),
+                         f"C{cfg} window @({x0},{y0}) of the whole frame")

@@ -35,8 +35,33 @@ if os.environ.get("RT_TRY_CHILD"):
             rt.sync(); ts.append((time.perf_counter() - t0) / k * 1e3)
         col, pos, nrm = rt.readback()
         crc = zlib.crc32(nrm.tobytes(), zlib.crc32(pos.tobytes(), zlib.crc32(col.tobytes())))
-        rt.set_variant(0x101); rt.render(p); rt.sync(); rt.render(p); rt.sync(); cold = rt.last_kernel_ms(); rt.set_variant(1)
-        print(f"RESULT C{cfg} {w}x{h}: median {np.median(ts):.4f} ms  min {min(ts):.4f}  raster-order {cold:.4f}  crc {crc:08x}", flush=True)
+        from opengl_raytracing_amd import layout as L
+        # frames whose inputs differ from each other (frameCount advances: the reference's default, TAA on) -- the SAME sequence
+        # under the default scheduler (order predicted per frame) and in raster order; back to back, and one frame at a time
+        seq = [L.copy_params(p, frameCount=sc.frame_count + 1 + i) for i in range(max(k, 12))]
+        res = {}
+        for mode, name in ((1, "auto"), (0x101, "raster")):
+            rt.set_variant(mode)
+            for q in seq[:4]:
+                rt.render(q)
+            rt.sync(); t0 = time.perf_counter()
+            for q in seq:
+                rt.render(q)
+            rt.sync(); res[name] = (time.perf_counter() - t0) / len(seq) * 1e3
+            lat = []
+            for q in seq[:10]:
+                rt.sync(); t0 = time.perf_counter(); rt.render(q); rt.sync(); lat.append((time.perf_counter() - t0) * 1e3)
+            res[name + "_alone"] = float(np.mean(lat))
+        rt.set_variant(0x101)
+        for _ in range(3):
+            rt.render(p)
+        rt.sync(); t0 = time.perf_counter()
+        for _ in range(k):
+            rt.render(p)
+        rt.sync(); raster = (time.perf_counter() - t0) / k * 1e3
+        rt.set_variant(1)
+        print(f"RESULT C{cfg} {w}x{h}: static {np.median(ts):.4f} ms (raster {raster:.4f}) | new frames: predicted {res['auto']:.4f}  raster {res['raster']:.4f} | "
+              f"one at a time: predicted {res['auto_alone']:.4f}  raster {res['raster_alone']:.4f}  crc {crc:08x}", flush=True)
     sys.exit(0)
 
 os.makedirs("/tmp/rtx", exist_ok=True)
