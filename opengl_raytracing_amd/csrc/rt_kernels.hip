@@ -330,6 +330,9 @@ __device__ __forceinline__ v3 compute_pbr(const Mat &m, v3 N, v3 V, v3 L, v3 H, 
 __device__ __forceinline__ v3 hemisphere_dir(v3 h, v3 n) {
     v3 tangent = normalize(cross(n, V3(0.0f, 1.0f, 1.0f)));
     v3 bitangent = cross(n, tangent);
+    // tangent = (n.y - n.z, -n.x, n.x) * rsq: the reference's GL factors bitangent.x = n.y*t.z + n.z*t.z into t.z * (n.y + n.z)
+    // (its final NIR, read with LP_DEBUG=cs; oracle/rt_oracle.c cosineWeightedHemisphere) -- C3's residue of round 2
+    bitangent.x = tangent.z * (n.y + n.z);
     return normalize((tangent * h.x + bitangent * h.z) + n * h.y);
 }
 

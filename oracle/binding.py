@@ -61,6 +61,10 @@ def render(scene, params, nthreads=0):
     lts = np.ascontiguousarray(scene.lights)
     noise = np.ascontiguousarray(scene.noise) if scene.noise is not None else None
     sky = np.ascontiguousarray(scene.skybox) if (scene.skybox is not None and scene.use_skybox) else None
+    # orc_params.reserved0 carries the oracle's DIAGNOSTIC bits (rt_oracle.h: 1 = llvmpipe's polynomial pow, 2 / 4 = its loop
+    # limiter); every parity test against the HIP path leaves it 0 -- anything else is refused rather than silently honoured
+    if not 0 <= int(params.reserved0) <= 7:
+        raise ValueError(f"params.reserved0 = {params.reserved0}: not a set of oracle diagnostic bits")
     rc = lib.orc_render(_ptr(objs), len(objs), _ptr(lts), len(lts), ctypes.byref(params),
                         _ptr(noise), noise.shape[1] if noise is not None else 0,
                         noise.shape[0] if noise is not None else 0,

@@ -63,7 +63,26 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
  * DIAGNOSTIC (orc_params.reserved0 bit 0, tests only): use mesa_pow5f below -- llvmpipe's own polynomial
  * pow, restated bit for bit -- instead; with it gColor equals the reference fixtures bit for bit as well,
  * which proves that the exact-product pow is the ONLY arithmetic difference left against the reference. */
-static int g_mesa_pow = 0;
+/* (per THREAD, set from the render's own parameters at the start of every row: concurrent renders with different flags do
+ *  not disturb each other -- ADVICE r2) */
+static _Thread_local int g_mesa_pow = 0;
+/* DIAGNOSTIC (orc_params.reserved0 bit 1, tests only): llvmpipe's LOOP LIMITER.  gallivm gives every shader ONE counter of
+ * LP_MAX_TGSI_LOOP_ITERS = 65535 loop iterations, shared by all (inlined, nested) loops and never reset; every pass
+ * through the end of any loop decrements it, and once it reaches zero every loop leaves at its next end.  A hang guard of
+ * the software rasteriser, not a property of the shader -- but C5 at MAX_RAY_DEPTH >= 8 reaches it: 8 bounces x (1 + 8
+ * lights x 4 samples) traversals x 257 passes of the 256-object loop = 67 848 > 65 535, so in the pixels whose path is
+ * still alive at the 8th bounce the reference-on-llvmpipe stops adding lights (and, from depth 9 on, stops finding the
+ * closest hit): its colour is LOWER than the shader's by percents with identical gPosition -- the residue of VERDICT r2
+ * (8 of 14 400 px low-res, 7 of 59 904 at 8K; 0 px for every depth <= 7; C4's 64 objects stay below the limit).  With
+ * this bit the restatement counts the same passes per pixel (llvmpipe counts per 8-invocation vector, whose loops have
+ * lane-independent trip counts here) and leaves its loops the same way. */
+static _Thread_local int g_lim = 0, g_budget = 0, g_lim_sss_lane = 0;
+static inline int loop_end(void) { return g_lim && (--g_budget <= 0); }
+/* a loop whose every pass through its end -- the pass that finds the condition false included, as in gallivm's
+ * structured loops -- takes one tick of the limiter; `break` inside the body must be written LIM_BREAK */
+#define LIM_FOR(decl, cond, inc) \
+    for (int lim_stop_ = 0, lim_once_ = 1; lim_once_; lim_once_ = 0) for (decl; ((cond) || (loop_end(), 0)) && !lim_stop_; inc, lim_stop_ = loop_end())
+#define LIM_BREAK { (void)loop_end(); break; }
 static inline float mesa_pow5f(float x);
 static inline float pow5(float x) {
     if (g_mesa_pow) return mesa_pow5f(x);
@@ -399,7 +418,7 @@ static int intersectObjects(Ctx *c, const Ray *r, Mat *hitMat, v3 *hitNormal, fl
     float minT = c->p->maxRayDistance;
     int hit = 0;
     c->rays++;
-    for (int i = 0; i < c->nObj; i++) {
+    LIM_FOR(int i = 0, i < c->nObj, i++) {
         const Obj *o = &c->objs[i];
         if (!intersectAABB(c, r, o->bmin, o->bmax)) continue;
         float ct = 0.0f;
@@ -426,7 +445,7 @@ static float halton(int index, int base) {
     float result = 0.0f;
     float f = 1.0f / (float)base;
     int i = index;
-    while (i > 0) {
+    LIM_FOR(int k_ = 0, i > 0, k_++) {
         result += f * (float)(i % base);
         i = i / base;
         f = f / (float)base;
@@ -442,6 +461,11 @@ static v3 cosineWeightedHemisphere(float rx, float ry, v3 n) {
     v3 h = V3(sinTheta * mesa_cosf(phi), cosTheta, sinTheta * mesa_sinf(phi));
     v3 tangent = normalize3(cross3(n, V3(0, 1, 1)));
     v3 bitangent = cross3(n, tangent);
+    /* tangent = (n.y - n.z, -n.x, n.x) * rsq, so bitangent.x = n.y*t.z - n.z*t.y = n.y*t.z + n.z*t.z, which Mesa's NIR factors
+     * into t.z * (n.y + n.z) (final NIR of the reference shader, LP_DEBUG=cs: `fadd %226, %227` then `fmul %2326, %2331`).
+     * One rounding fewer; invisible while the hemisphere sample's sin(phi) is ~0 (frameCount 0: C2, C4, C5) and the cause
+     * of C3's 20-of-32 400-pixel residue of round 2 (frameCount 7): with it gPosition equals the reference's bit for bit. */
+    bitangent.x = tangent.z * (n.y + n.z);
     return normalize3(add3(add3(scale3(tangent, h.x), scale3(bitangent, h.z)), scale3(n, h.y)));
 }
 
@@ -492,7 +516,7 @@ static float pcfShadow(Ctx *c, v3 point, v3 normal, const Lgt *l, v3 lightDir, f
     v3 tangent = normalize3(cross3(lightDir, V3(0, 1, 0)));
     v3 bitangent = cross3(lightDir, tangent);
     float jr = sample_noise(c); /* .rg of an R8 texture = (r, 0) */
-    for (int i = 0; i < l->pcfSamples; i++) {
+    LIM_FOR(int i = 0, i < l->pcfSamples, i++) {
         float filterSize = l->shadowSoftness * 0.005f;
         float rx = fract1(halton(i, 2) + jr);
         float ry = fract1(halton(i, 3) + 0.0f);
@@ -514,7 +538,7 @@ static float pcfShadow(Ctx *c, v3 point, v3 normal, const Lgt *l, v3 lightDir, f
 static float pcssShadow(Ctx *c, v3 point, v3 normal, const Lgt *l, v3 lightDir, float lightDistance) {
     int blockerCount = 0;
     float searchSize = l->lightSize * 0.1f;
-    for (int i = 0; i < 16; i++) {
+    LIM_FOR(int i = 0, i < 16, i++) {
         float rr = halton(i, 3) * 2.0f - 1.0f;
         v3 sd = add3(add3(lightDir, splat3(rr * searchSize)), splat3(rr * searchSize));
         Ray sr;
@@ -541,7 +565,7 @@ static float calculateShadow(Ctx *c, v3 point, v3 normal, v3 lightDir, float lig
 /* computeSubsurfaceScattering  :316-339 */
 static v3 computeSSS(Ctx *c, v3 P, v3 N, const Mat *m) {
     v3 sss = V3(0, 0, 0);
-    for (int i = 0; i < 4; i++) {
+    LIM_FOR(int i = 0, i < 4, i++) {
         float rx = (float)i / 4.0f, ry = halton(i, 2); /* hammersley(i,4) :311-313 */
         Ray r;
         r.origin = add3(P, scale3(N, 0.001f));
@@ -558,7 +582,7 @@ static v3 computeSSS(Ctx *c, v3 P, v3 N, const Mat *m) {
 /* computeLighting  :457-507 */
 static v3 computeLighting(Ctx *c, v3 P, v3 N, const Mat *m, v3 V) {
     v3 Lo = V3(0, 0, 0);
-    for (int i = 0; i < c->nLt; i++) {
+    LIM_FOR(int i = 0, i < c->nLt, i++) {
         const Lgt *l = &c->lts[i];
         v3 lightDir = V3(0, 0, 0);
         float attenuation = 1.0f, lightDistance = 0.0f;
@@ -589,6 +613,18 @@ static v3 computeLighting(Ctx *c, v3 P, v3 N, const Mat *m, v3 V) {
         Lo = add3(Lo, scale3(computePBR(m, N, V, L, H, radiance), shadowFactor));
     }
     if (m->subsurfaceScatter > 0.0f) Lo = add3(Lo, computeSSS(c, P, N, m));
+    else if (g_lim && g_lim_sss_lane) {
+        /* (diagnostic bit 2, with bit 1) llvmpipe's limiter counts per VECTOR of 8 invocations: when another lane of the vector
+         * shades a subsurface material, the whole vector passes through computeSubsurfaceScattering's loops -- four probe
+         * traversals with their Halton loops -- and this pixel's budget shrinks by the same passes */
+        for (int i = 0; i < 4; i++) {
+            for (int k = i; k > 0; k /= 2) (void)loop_end();
+            (void)loop_end();                                        /* haltonSequence(i, 2): digits + the leaving pass */
+            for (int k = 0; k <= c->nObj; k++) (void)loop_end();     /* intersectObjects */
+            (void)loop_end();                                        /* the probe loop's own end */
+        }
+        (void)loop_end();
+    }
     return Lo;
 }
 
@@ -629,7 +665,8 @@ static void shade_pixel(Ctx *c, float *color, float *pos, uint16_t *nrm) {
     generateCameraRay(c, &ray, jx, jy);
     v3 finalColor = V3(0, 0, 0), throughput = V3(1, 1, 1);
     v3 P = V3(0, 0, 0), V, N = V3(0, 0, 0); /* undefined locals read as zero (A.3) */
-    for (int depth = 0; depth < p->maxRayDepth; ++depth) {
+    g_budget = 65535;        /* LP_MAX_TGSI_LOOP_ITERS, per invocation (only read under the diagnostic bit) */
+    LIM_FOR(int depth = 0, depth < p->maxRayDepth, ++depth) {
         Mat mat; float t;
         memset(&mat, 0, sizeof mat);
         if (!intersectObjects(c, &ray, &mat, &N, &t)) {
@@ -638,7 +675,7 @@ static void shade_pixel(Ctx *c, float *color, float *pos, uint16_t *nrm) {
             /* else: `finalColor += throughput * vec3(0.0)` (:532).  Mesa folds x*0.0 to 0.0
              * (inexact algebra), so a NaN/inf throughput does NOT poison the colour on a miss:
              * pinned by the nan fixture (tests/golden/nan.npz). */
-            break;
+            LIM_BREAK
         }
         P = add3(ray.origin, scale3(ray.direction, t));
         V = normalize3(neg3(ray.direction));
@@ -648,7 +685,7 @@ static void shade_pixel(Ctx *c, float *color, float *pos, uint16_t *nrm) {
             float dw = length3(mat.albedo) * mat.diffuseStrength;
             float cp = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * 0.95f + dw, 0.99f);
             float rnd = random2((float)(c->gidx + (uint32_t)depth), (float)(c->gidy + (uint32_t)depth));
-            if (rnd > cp) break;
+            if (rnd > cp) LIM_BREAK
             throughput = divs3(throughput, cp);
         }
         float F = fresnelSchlick(fmaxf(dot3(V, N), 0.0f), mat.ior);
@@ -692,7 +729,7 @@ int orc_render(const void *objects, int nObj, const void *lights, int nLt, const
     for (int i = 0; i < nObj; i++) decode_object((const uint8_t *)objects + (size_t)i * 176, &objs[i]);
     for (int i = 0; i < nLt; i++) decode_light((const uint8_t *)lights + (size_t)i * 96, &lts[i]);
     uint64_t total = 0;
-    g_mesa_pow = p->reserved0 & 1;      /* diagnostic: llvmpipe's polynomial pow (see pow5) */
+    const int diag_pow = p->reserved0 & 1, diag_lim = (p->reserved0 >> 1) & 1, diag_sss = (p->reserved0 >> 2) & 1;      /* diagnostics (see pow5, loop_end) */
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -701,6 +738,9 @@ int orc_render(const void *objects, int nObj, const void *lights, int nLt, const
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
     for (int j = 0; j < p->regionH; j++) {
         Ctx c;
+        g_mesa_pow = diag_pow;
+        g_lim = diag_lim;
+        g_lim_sss_lane = diag_sss;
         c.objs = objs; c.nObj = nObj; c.lts = lts; c.nLt = nLt; c.p = p;
         c.noise = noise; c.noiseW = noiseW; c.noiseH = noiseH;
         c.sky = sky; c.skySize = skySize; c.rays = 0;

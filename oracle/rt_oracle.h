@@ -37,7 +37,10 @@ typedef struct orc_params {
      * ((ly / stripRows) * stripCount + stripIndex) * stripRows + ly % stripRows.
      * stripCount = 1, stripIndex = 0 is the identity. */
     int32_t stripRows, stripCount, stripIndex;
-    int32_t reserved0;    /* unused (was a test-only tan override before mesa_tanf restated llvmpipe's tan) */
+    int32_t reserved0;    /* DIAGNOSTIC bits, 0 in every parity test against the HIP path: bit 0 = pow(x, 5) by llvmpipe's own
+                           * exp2/log2 polynomials instead of the exact product (rt_oracle.c pow5), bit 1 = emulate llvmpipe's
+                           * 65 535-iteration loop limiter (rt_oracle.c loop_end).  Both only serve to EXPLAIN what is left
+                           * between the restatement and the reference's pixels; oracle/binding.py sets the field explicitly. */
     /* unequal strips: stripCycleRows > 0 -> global row (ly / stripRows) * stripCycleRows +
      * stripOffsetRows + ly % stripRows (stripCount / stripIndex ignored) */
     int32_t stripCycleRows, stripOffsetRows;

@@ -88,9 +88,10 @@ def test_c2_full_frame_properties(tracer, host, oracle):
 # reference's GL does (csrc/rt_mesa_math.h), so the geometry surfaces must be the reference's BIT FOR BIT and gColor
 # within north_star's 1e-4 (the one arithmetic difference left is pow(x,5): exact product here, exp2(5 log2 x)
 # polynomials on llvmpipe, <= 1.3e-6 apart).  fixture -> (min bit-exact fraction of gPosition and of gNormal,
-# min fraction of gColor pixels within 1e-4 relative).  Measured residue: C3 20 px of 32 400 (NEAREST noise texel at
-# exact texel boundaries), C5 8 px of 14 400 (8th loop iteration, see tests/test_oracle_golden.py).
-REF_GATES = {"c1": (1.0, 1.0), "c2": (1.0, 1.0), "c3": (0.999, 0.9999), "c4": (1.0, 0.9999), "c5": (1.0, 0.999), "nan": (1.0, 1.0)}
+# min fraction of gColor pixels within 1e-4 relative).  The one residue left is an artefact of llvmpipe, not of the shader:
+# C5 at depth 8, 8 px of 14 400 whose reference colour is cut short by gallivm's 65 535-iteration loop limiter (explained and
+# emulated in tests/test_oracle_golden.py); C3's 20 px of round 2 are gone (NIR's factored bitangent.x, restated).
+REF_GATES = {"c1": (1.0, 1.0), "c2": (1.0, 1.0), "c3": (1.0, 1.0), "c4": (1.0, 1.0), "c5": (1.0, 0.999), "nan": (1.0, 1.0)}
 
 
 def _frac_exact(a, b):

@@ -9,12 +9,22 @@ and NO test-only knob is involved any more.  Gates per fixture:
 * gPosition / gNormal BIT FOR BIT (everything geometric is the same IEEE arithmetic in the same order);
 * gColor within 1e-4 relative: the only arithmetic difference left is pow(x,5) -- exact product here and in the
   HIP kernel, exp2(5 log2 x) polynomials on llvmpipe (<= 1.3e-6 apart);
-* DIAGNOSTIC: with llvmpipe's polynomial pow restated too (orc_params.reserved0 bit 0) gColor is bit-exact as well
-  on >= 99.9 % of pixels (C5, whose paths end in bilinear skybox taps: >= 90 %), which proves the claim above.
-* Known residue, measured and classified: C3 (noise-texture jitter) has 20 of 32 400 px whose gPosition differs
-  (NEAREST texel choice at exact texel boundaries); C5 at depth 8 has 8 of 14 400 px whose colour differs by
-  percents with identical gPosition -- they appear only when MAX_RAY_DEPTH >= 8 (0 px at depth <= 7), always as
-  oracle > reference: llvmpipe evaluates the 8th iteration of the (then no longer fully unrolled) loop differently.
+* DIAGNOSTIC: with llvmpipe's polynomial pow restated too (orc_params.reserved0 bit 0) gColor is BIT-EXACT as well on
+  100 % of the pixels of C1..C4 and the NaN scene (C5, whose paths end in bilinear skybox taps: >= 90 %), which proves
+  the claim above.
+* The two residues of round 2 are EXPLAINED, both from the reference shader's final NIR as llvmpipe
+  compiles it (LP_DEBUG=cs on the harness):
+  - C3 (20 of 32 400 px, gPosition an ulp off after a diffuse bounce): cosineWeightedHemisphere's bitangent.x =
+    n.y*t.z - n.z*t.y with t.y = -t.z is FACTORED by NIR into t.z * (n.y + n.z) -- one rounding fewer, invisible while
+    the hemisphere sample's sin(phi) is ~0 (frameCount 0: C2, C4, C5), visible at C3's frameCount 7.  Restated (oracle
+    and HIP): C3's gPosition is the reference's on 100 %.
+  - C5 at MAX_RAY_DEPTH >= 8 (8 of 14 400 px, colour LOWER in the reference by percents, identical gPosition): gallivm
+    gives a shader ONE counter of 65 535 loop iterations shared by all its loops (LP_MAX_TGSI_LOOP_ITERS, a hang guard);
+    8 bounces x (1 + 8 lights x 4 samples) traversals x 257 passes of the 256-object loop = 67 848 exceeds it, so in
+    pixels whose path is alive at the 8th bounce the reference-on-llvmpipe stops adding lights.  An artefact of the
+    software rasteriser, not of the shader (a GPU driver has no such counter) -- class (iv), NOT restated in the product.
+    test_c5_depth8_residue_is_llvmpipes_loop_limiter emulates the counter (reserved0 bit 1) and checks that it accounts
+    for the residue.
 """
 import numpy as np
 import pytest
@@ -26,9 +36,9 @@ from opengl_raytracing_amd import layout as L
 #             min gColor BIT-EXACT fraction with the polynomial-pow diagnostic)
 GATES = {
     "c1": (1.0, 1.0, 1.0),
-    "c2": (1.0, 1.0, 0.9999),
-    "c3": (0.999, 1.0, 0.999),
-    "c4": (1.0, 1.0, 0.999),
+    "c2": (1.0, 1.0, 1.0),
+    "c3": (1.0, 1.0, 1.0),
+    "c4": (1.0, 1.0, 1.0),
     "c5": (1.0, 0.999, 0.90),
     "nan": (1.0, 1.0, 1.0),
 }
@@ -138,3 +148,39 @@ def test_c5_at_7680x4320_windows_against_reference(oracle):
     print(f"c5 8K: gPosition exact {ep / n_px:.6f} gNormal exact {en / n_px:.6f} gColor pass {okc / n_px:.6f} ({n_px} px)")
     assert ep / n_px >= 0.9995 and en / n_px >= 0.9995
     assert okc / n_px >= 0.999
+
+
+def test_c5_depth8_residue_is_llvmpipes_loop_limiter(oracle):
+    """C5's colour residue at MAX_RAY_DEPTH >= 8 (module docstring) is llvmpipe's 65 535-iteration loop limiter:
+    (a) it needs depth >= 8 AND 256 objects AND 8 shadowed lights -- 8 x 33 x 257 > 65 535 >= 7 x 33 x 257 + 257;
+    (b) with the counter emulated per pixel (reserved0 bit 1) five of the eight pixels fall within 1e-4 of the reference and two
+        of them reproduce it to the bit pattern of their position in the frame (llvmpipe counts per 8-invocation VECTOR: a
+        neighbouring lane on a subsurface material spends budget for the whole vector -- bit 2 emulates that extreme; the
+        remaining pixels' reference colours lie BETWEEN the two emulations);
+    (c) every pixel outside that set is untouched by the emulation, and at depth 7 nothing differs at all."""
+    assert 8 * 33 * 257 > 65535 >= 7 * 33 * 257 + 257
+    g = load_golden("c5")
+    sc = GoldenScene(g)
+    p = params_from_bytes(g["lowres_params"])
+    assert p.maxRayDepth == 8 and len(sc.objects) == 256 and len(sc.lights) == 8
+    ref = g["lowres_color"]
+    cols = {}
+    for flags in (0, 2, 6):
+        q = L.copy_params(p)
+        q.reserved0 = flags
+        cols[flags] = oracle.render(sc, q)[0]
+    fail = {f: ~compare_surface(cols[f], ref)["ok_mask"] for f in cols}
+    assert int(fail[0].sum()) == 8
+    assert int((fail[0] & ~fail[2]).sum()) >= 5, "the per-pixel limiter must bring at least five residue pixels within 1e-4"
+    # the pixels neither variant brings within 1e-4: the reference lies between the two emulations (per-vector counting)
+    stubborn = fail[0] & fail[2] & fail[6]
+    lum = lambda a: a[..., :3].sum(-1)
+    lo, hi = np.minimum(lum(cols[2]), lum(cols[6])), np.maximum(lum(cols[2]), lum(cols[6]))
+    assert ((lum(ref)[stubborn] >= lo[stubborn] * (1 - 1e-4)) & (lum(ref)[stubborn] <= hi[stubborn] * (1 + 1e-4))).all()
+    # the emulation touches only pixels whose path is alive at the 8th bounce (a handful), never the rest of the frame
+    assert int((cols[2] != cols[0]).any(-1).sum()) <= 40
+    # and nothing of this exists at depth 7
+    q7 = L.copy_params(p, maxRayDepth=7)
+    c7 = oracle.render(sc, q7)[0]
+    q7.reserved0 = 2
+    assert np.array_equal(oracle.render(sc, q7)[0], c7, equal_nan=True)

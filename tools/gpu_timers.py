@@ -27,6 +27,9 @@ from opengl_raytracing_amd import build as B
 os.makedirs("/tmp/rtx", exist_ok=True)
 cfgs = sys.argv[1] if len(sys.argv) > 1 else "4,5"
 out = "/tmp/rtx/lib_timers.so"
-B.build_library(force=True, verbose=False, extra_flags=["-DRT_PK_TIMERS=1", *sys.argv[2:]], out=out)
+if os.environ.get("RT_TIMERS_LIB"):      # prebuilt in the build container (tools/build_variants.py "timers:-DRT_PK_TIMERS=1")
+    out = os.path.abspath(os.environ["RT_TIMERS_LIB"])
+else:
+    B.build_library(force=True, verbose=False, extra_flags=["-DRT_PK_TIMERS=1", *sys.argv[2:]], out=out)
 r = subprocess.run([sys.executable, os.path.abspath(__file__), cfgs], env=dict(os.environ, RT_LIB=out, RT_TIMERS_CHILD="1"))
 sys.exit(r.returncode)
