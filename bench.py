@@ -42,6 +42,10 @@ Rank 0 prints ONE JSON line.  What the fields mean (VERDICT r1 asked for a recor
   GLSL on Mesa llvmpipe (static record produced by tools/time_reference_llvmpipe.py in the build container --
   /root/reference cannot travel to the GPU box).
 * `configs_extra` = the same measurement for C3, C4, C5 (fewer steps), so they stop being prose.
+* N > 1 only, `peer_store` = the same frame on the same N devices from ONE process (rt_mgpu_*, csrc/rt_mgpu.cpp): every
+  device's kernel stores its strips straight into device 0's frame over xGMI, no wire format, no gather, no re-assembly.
+  Measured by a child process of rank 0 after the ranks' own measurement (they wait on the rendezvous store, off the GPUs),
+  under a timeout; reported BESIDE `value`, never instead of it (the contract's launch is one process per GPU).
 """
 import argparse
 import hashlib
@@ -276,6 +280,83 @@ def single_record(cfg, r, steps, warmup, src_hash):
     return out
 
 
+def peer_store_measure(devices, cfg, steps, warmup):
+    """The frame of config `cfg` on `devices` from this one process: rt_mgpu_render, image-addressed peer stores into device 0."""
+    from opengl_raytracing_amd import host, scenes
+    sc = scenes.make_scene(cfg, host.generate_aabb)
+    p = sc.params()
+    with host.RayTracer(devices[0]) as rt:
+        rt.load(sc)
+        rays = rt.count_rays(p)
+        rt.render(p)
+        ref = rt.readback()
+    with host.MultiGpuRayTracer(devices, strip_rows=8) as mg:
+        mg.load(sc)
+        for _ in range(max(3, warmup)):
+            mg.render(p)
+        mg.sync()
+        got = mg.readback()
+        same = all(np.array_equal(g.view(np.uint8), r.view(np.uint8)) for g, r in zip(got, ref))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mg.render(p)
+        mg.sync()
+        el = time.perf_counter() - t0
+        lat = 0.0
+        n_lat = max(3, min(steps, 10))
+        for _ in range(n_lat):
+            c0 = time.perf_counter()
+            mg.render(p)
+            mg.sync()
+            lat += time.perf_counter() - c0
+        per_dev = [round(float(x), 4) for x in mg.last_ms()]
+    return {"workload": workload_name(cfg, sc), "n_devices": len(devices), "devices": list(devices), "steps": steps,
+            "ms_per_step": round(el / steps * 1e3, 4), "value_mray_s": round(rays * steps / el / 1e6, 1),
+            "frame_latency_ms": round(lat / n_lat * 1e3, 4), "last_frame_kernel_ms_per_device": per_dev,
+            "assembled_frame_equals_single_gpu_render": bool(same),
+            "how": "one process, one context per device, interleaved 8-row strips, every kernel stores gColor / gPosition / "
+                   "gNormal at image addresses of device 0's frame (peer access over xGMI); frames issued back to back, "
+                   "wall clock over `steps` frames between two device syncs"}
+
+
+def peer_store_child(args):
+    """`bench.py --peer-store-child N`: prints one JSON object; run by rank 0 of an N > 1 bench (or by hand)."""
+    import torch
+    devs = ([int(x) for x in args.peer_store_devices.split(",")] if args.peer_store_devices
+            else list(range(args.peer_store_child)))
+    n_vis = torch.cuda.device_count()
+    if max(devs) >= n_vis:
+        print(json.dumps({"error": f"{len(devs)} devices asked for, {n_vis} visible to this process"}), flush=True)
+        return
+    out = {}
+    for c in [args.config] + [int(x) for x in args.extra_configs.split(",") if x.strip() and x.strip().lower() != "none"]:
+        k = args.steps if c == args.config else max(3, min(args.steps, 10))
+        try:
+            out[f"c{c}"] = peer_store_measure(devs, c, k, args.warmup if c == args.config else 2)
+        except Exception as e:       # reported, never fatal for the bench line
+            out[f"c{c}"] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
+
+
+def run_peer_store_child(world, cfg, extra, steps, warmup, timeout_s=300):
+    """Rank 0: the peer-store measurement in a child process (own HIP contexts on all N devices) under a timeout."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--peer-store-child", str(world), "--config", str(cfg),
+           "--extra-configs", ",".join(str(c) for c in extra) or "none", "--steps", str(steps), "--warmup", str(warmup)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child exit {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"child exceeded {timeout_s} s and was killed"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,7 +381,17 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 control-flow rehearsal on a 1-GPU box: every rank uses cuda:0 and the gather goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
+    ap.add_argument("--peer-store-child", type=int, default=0,
+                    help="internal / by hand: measure the single-process peer-store path (rt_mgpu_*) on devices 0..N-1 and print it")
+    ap.add_argument("--peer-store-devices", default="", help="with --peer-store-child: explicit device list, e.g. 0,0,0,0 "
+                    "(the N-way plan on one GPU: a control-flow rehearsal, not a measurement)")
+    ap.add_argument("--no-peer-store", action="store_true", help="N > 1: skip the peer-store measurement")
     args = ap.parse_args()
+
+    if args.peer_store_child:
+        if args.extra_configs == "3,4,5":
+            args.extra_configs = "5"
+        return peer_store_child(args)
 
     import torch
     import torch.distributed as dist
@@ -622,6 +713,28 @@ def main():
     for c in extra:
         k = max(3, min(args.steps, 10))
         extras[f"c{c}"] = run_config(c, k, 2, autotune=False)
+    peer = None
+    if world > 1 and not args.no_peer_store and not args.rehearse_on_one_gpu:
+        # the other ranks wait on the rendezvous store (host side): an RCCL barrier would spin on their GPUs meanwhile
+        torch.cuda.synchronize()
+        dist.barrier()
+        store = None
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            pass
+        if rank == 0:
+            peer = run_peer_store_child(world, args.config, extra, args.steps, args.warmup)
+            if store is not None:
+                store.set("bench_peer_store_done", "1")
+        elif store is not None:
+            import datetime
+            try:
+                store.wait(["bench_peer_store_done"], datetime.timedelta(seconds=420))
+            except Exception:
+                pass
+        if store is None:
+            dist.barrier()
     if rank == 0:
         out = {"metric": "Mray/s", "value": head["value_mray_s"], "unit": "Mray/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -643,6 +756,8 @@ def main():
                 out[k] = v
         if extras:
             out["configs_extra"] = extras
+        if peer is not None:
+            out["peer_store"] = peer
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "rt_fastmath.h"
+
 #ifndef RT_TAA_LDS
 #define RT_TAA_LDS 0   // 1: stage the current-frame tile (+halo) in LDS; 0: neighbourhood straight from L1/L2.
 #endif                // Measured equal within noise (29-31 us @1080p for every tile shape): the pass is limited by the
@@ -497,7 +499,12 @@ __global__ __launch_bounds__(256) void rt_ssao_kernel(const float4 *__restrict__
         ox = ox * 0.5f + 0.5f;
         oy = oy * 0.5f + 0.5f;
         const float sampleDepth = depth[(size_t)ssao_nearest_repeat(oy, H) * W + ssao_nearest_repeat(ox, W)];
-        const float x = 0.5f / fabsf(fp.z - sampleDepth);
+        // 0.5 / |dz| = RN(1 / |dz|) * 0.5: halving is exact while reciprocal and product are normal numbers (|dz| in [2^-126, 2^125]),
+        // and rtf::rcp is the correctly rounded reciprocal without the compiler's 11-instruction division (rt_fastmath.h); any
+        // other |dz| -- 0, denormal, huge, NaN -- takes the IEEE division (wave-uniform branch, never taken on real G-buffers)
+        const float adz = fabsf(fp.z - sampleDepth);
+        float x = rtf::rcp(adz) * 0.5f;
+        if (__builtin_amdgcn_ballot_w64(!((adz >= 0x1p-126f) & (adz <= 0x1p125f))) != 0ull) x = 0.5f / adz;
         const float tt = fminf(fmaxf(x, 0.0f), 1.0f);
         const float rangeCheck = tt * (tt * (3.0f - 2.0f * tt));
         occlusion += (sampleDepth >= pz + 0.025f ? 1.0f : 0.0f) * rangeCheck;
