@@ -33,9 +33,13 @@ Rank 0 prints ONE JSON line.  What the fields mean (VERDICT r1 asked for a recor
   same region by its first and last event, and the duration `roofline.frac` is computed from.
 * The headline frames are identical, so from the third on they run in the order sorted from their MEASURED tile costs.
   `free_running` = the same workload with frameCount advancing every frame (the reference's default: TAA on,
-  ForwardShadingPipeline.cpp:254): every frame's inputs are new, its tile order is PREDICTED from them in-stream
-  (rt_predict_tiles_kernel), no history is used.  `cold_frame_ms` = such new frames one at a time with a device sync
-  in between (nothing overlaps, predictor pass included); `raster_order_ms` = the scheduler switched off.
+  ForwardShadingPipeline.cpp:254): every frame's inputs are new.  frameCount only rotates the bounce sample all pixels
+  share, with period 64 (raytracingCs.glsl:557), so the scheduler keeps one measured tile order per phase: `free_running`
+  is the steady state (second period on: each frame runs in the order measured 64 frames earlier),
+  `free_running_first_period` the first 64 new frames (all-phase average order).  Frames of >= 49 152 tiles without any
+  measured order run in an order PREDICTED from their own inputs (rt_predict_tiles_kernel).  `cold_frame_ms` = new
+  steady-state frames one at a time with a device sync in between (nothing overlaps; host launch + sync included);
+  `raster_order_ms` = the scheduler switched off.
 * `pipelined` = the headline frames with two in flight on two streams (the ABI is asynchronous): frame k's tail
   overlaps frame k+1's head.  Throughput, not latency.
 * `cpu_baseline` = the oracle port timed on this box's host cores; `cpu_baseline_reference` = the reference's own
@@ -197,37 +201,48 @@ def measure_single(cfg, steps, warmup, variant, dev_index, with_modes=True):
                          "p90": round(float(np.percentile(per_frame, 90)), 4), "min": round(float(per_frame.min()), 4),
                          "max": round(float(per_frame.max()), 4)})
     if with_modes:
-        # (1) frameCount advancing every frame, as in the reference with TAA on: every frame is new (predicted order, no history);
-        #     the rays differ per frame, so count each
+        # (1) frameCount advancing every frame, as in the reference with TAA on (ForwardShadingPipeline.cpp:254).  Every frame's inputs
+        #     are new and its rays differ, so each timed frame is counted.  The bounce sample all pixels share is (nearly) periodic in
+        #     frameCount with period 64, and the scheduler keeps one measured tile order per phase (rt_abi.cpp): the FIRST period runs
+        #     in the all-phase average order, later ones in the order measured 64 frames earlier.  Both are reported.
         n_free = min(steps, 64)
         fc0 = sc.frame_count
-        frames = [L.copy_params(base, frameCount=fc0 + 1 + k) for k in range(n_free)]
-        free_rays = [rt.count_rays(p) for p in frames]
+        frames = [L.copy_params(base, frameCount=fc0 + 1 + k) for k in range(8 + 64 + n_free + 16)]
+
+        def timed(fr):
+            rays = [rt.count_rays(p) for p in fr]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for p in fr:
+                render(p)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            return {"ms_per_step": round(t / len(fr) * 1e3, 4), "frames": len(fr), "value_mray_s": round(sum(rays) / t / 1e6, 1),
+                    "rays_reference_per_frame_min_max": [int(min(rays)), int(max(rays))]}
         for p in frames[:8]:
             render(p)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for p in frames:
+        first = timed(frames[8:8 + n_free])
+        for p in frames[8 + n_free:72]:          # the rest of the first period, untimed
             render(p)
-        torch.cuda.synchronize()
-        t_free = time.perf_counter() - t0
-        res["free_running"] = {"ms_per_step": round(t_free / n_free * 1e3, 4), "frames": n_free,
-                               "value_mray_s": round(sum(free_rays) / t_free / 1e6, 1),
-                               "rays_reference_per_frame_min_max": [int(min(free_rays)), int(max(free_rays))],
-                               "note": "frameCount advances every frame (reference default, TAA on: ForwardShadingPipeline.cpp:254): it "
-                                       "rotates the bounce sample all pixels share, every frame's inputs are new and its tile order is "
-                                       "predicted from them (no history)"}
-        # (2) the same new frames one at a time (device sync in between): what the first frame of a new view costs, predictor included
+        res["free_running"] = timed(frames[72:72 + n_free])
+        res["free_running"]["note"] = ("frameCount advances every frame (reference default, TAA on: ForwardShadingPipeline.cpp:254): every frame's "
+                                       "inputs are new; steady state = from the second 64-frame period of frameCount on (about one second of "
+                                       "the application), when each frame runs in the tile order measured on the frame 64 earlier")
+        first["note"] = "the first period of a free-running frameCount: no phase has been seen yet, tiles run in the all-phase average order"
+        res["free_running_first_period"] = first
+        # (2) new frames one at a time (device sync in between, nothing overlaps): what a new frame costs in that steady state
         n_cold = max(4, min(steps, 16))
+        cold = frames[72 + n_free:72 + n_free + n_cold]
+        cold_rays = [rt.count_rays(p) for p in cold]
         lat = []
-        for p in frames[:n_cold]:
+        for p in cold:
             torch.cuda.synchronize()
             c0 = time.perf_counter()
             render(p)
-            torch.cuda.synchronize()
+            stream.synchronize()                 # what the frame's consumer waits for (the scheduler's sort runs beside, on its own stream)
             lat.append((time.perf_counter() - c0) * 1e3)
         res["cold_frame_ms"] = round(float(np.mean(lat)), 4)
-        res["cold_frame_rays_reference_mean"] = int(np.mean(free_rays[:n_cold]))
+        res["cold_frame_rays_reference_mean"] = int(np.mean(cold_rays))
         # (3) scheduler off: raster tile order, the headline frame
         rt.set_variant((variant & 0xff) | 0x100)
         for _ in range(2):
@@ -274,7 +289,7 @@ def single_record(cfg, r, steps, warmup, src_hash):
            "step_ms_device": round(r["step_ms_dev"], 4), "frame_ms": r["frame_ms"]}
     # the roofline's duration is the timed region's own (the one `value` is computed from), by HIP events on the launch stream
     out.update(roofline_record(cfg, sc, n_px, r["rays_ref"], r["step_ms_dev"], load_counters(cfg), src_hash))
-    for k in ("free_running", "cold_frame_ms", "cold_frame_rays_reference_mean", "raster_order_ms", "pipelined"):
+    for k in ("free_running", "free_running_first_period", "cold_frame_ms", "cold_frame_rays_reference_mean", "raster_order_ms", "pipelined"):
         if k in r:
             out[k] = r[k]
     return out

@@ -99,6 +99,23 @@ struct rt_context {
     int dbgPredTiles = 0;
     bool feedback = true;
     unsigned fbPeriod = 32;                    // re-sort period in frames (RT_FB_PERIOD overrides, for measurements)
+    // Free-running frameCount (the reference with TAA on, ForwardShadingPipeline.cpp:254): frameCount enters the frame through
+    // hammersley(depth*64 + frameCount, 64) (:557) -- the bounce sample ALL pixels share -- whose azimuth is periodic in frameCount
+    // with period 64 and whose cos^2(theta) = halton2 repeats to within 2^-6.  A frame's tile costs therefore repeat, nearly, every
+    // 64 frames, while consecutive frames differ a lot (tools/gpu_phase_costs.py: list-scheduling makespan over the ideal, C2:
+    // 1.04 in the frame's own order, 1.06-1.09 in the order of the frame 64 earlier, 1.07-1.17 in the all-phase average order,
+    // 1.29-1.34 in raster order).  So once frameCount is seen advancing, every frame's costs go to its PHASE's buffer
+    // (frameCount mod 64) and are sorted, beside the following frames on a stream of their own, into that phase's order, which
+    // the frame 64 later runs in; phases not seen yet use the all-phase average order as before (the per-phase sorts feed it).
+    hipStream_t phaseStream = nullptr;
+    unsigned *dPhaseCost = nullptr, *dPhaseOrder = nullptr, *dPhaseSnap = nullptr;   // [64][phaseTiles], [64][phaseTiles], [phaseTiles]
+    size_t capPhase = 0;                       // tiles per phase the buffers hold
+    int phaseTiles = 0;                        // tiles per phase of the current geometry (0 = none)
+    hipEvent_t evPhase[64] = {};               // completion of the last sort into phase k's order
+    unsigned char phaseState[64] = {};         // 0 = no order, 1 = sort issued, 2 = seen complete
+    bool phaseOn = true;                       // RT_PHASE_ORDER=0 switches it off (measurements)
+    bool haveLastFc = false;
+    int lastFc = 0, freeRun = 0;               // consecutive scheduled launches whose frameCount differed from the previous one's
     std::string err;
 };
 
@@ -206,6 +223,7 @@ void build_frame(const rt_context *c, const rt_params *p, RtFrame *f) {
 
 hipError_t fb_sync_all(rt_context *c) {
     hipError_t e = hipStreamSynchronize(c->stream);
+    if (c->phaseStream && e == hipSuccess) e = hipStreamSynchronize(c->phaseStream);
     for (int i = 0; i < c->nFbStreams && e == hipSuccess; i++) e = hipEventSynchronize(c->fbStreams[i].last);
     for (int k = 0; k < 2 && e == hipSuccess; k++)
         if (c->evSort[k]) e = hipEventSynchronize(c->evSort[k]);
@@ -311,6 +329,10 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             c->fbCur = -1;
             c->sortPending = false;
             c->fbAge = 0;
+            // the phases' orders belong to the old geometry.  Sorts still queued on the phase stream finish before any
+            // sort of the new geometry (one stream), and an order is read only once its own sort has been seen complete.
+            memset(c->phaseState, 0, sizeof c->phaseState);
+            c->phaseTiles = 0;
         } else if (c->sortPending) {
             // The sort runs on the context's own stream, beside the frames; its order is adopted by the first launch
             // issued after it has completed, so no render stream waits for a sort in steady state.
@@ -369,6 +391,42 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
             c->dbgPredTiles = nTiles;
         }
     }
+    int phase = -1;
+    if (sched) {
+        c->freeRun = (c->haveLastFc && p->frameCount != c->lastFc) ? (c->freeRun < 1000 ? c->freeRun + 1 : 1000) : 0;
+        c->lastFc = p->frameCount;
+        c->haveLastFc = true;
+        if (c->phaseOn && c->schedMode == 2 && c->freeRun >= 2 && (size_t)nTiles * 64 * 2 * sizeof(unsigned) <= ((size_t)1 << 30)) {
+            if (!c->phaseStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->phaseStream, hipStreamNonBlocking));
+            if ((size_t)nTiles > c->capPhase) {
+                HIP_TRY(c, fb_sync_all(c));
+                for (unsigned **q : {&c->dPhaseCost, &c->dPhaseOrder, &c->dPhaseSnap}) {
+                    if (*q) HIP_TRY(c, hipFree(*q));
+                    *q = nullptr;
+                }
+                c->capPhase = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->dPhaseCost, (size_t)nTiles * 64 * sizeof(unsigned)));
+                HIP_TRY(c, hipMalloc((void **)&c->dPhaseOrder, (size_t)nTiles * 64 * sizeof(unsigned)));
+                HIP_TRY(c, hipMalloc((void **)&c->dPhaseSnap, (size_t)nTiles * sizeof(unsigned)));
+                c->capPhase = (size_t)nTiles;
+                c->phaseTiles = 0;
+            }
+            if (c->phaseTiles != nTiles) {       // first free-running frame of this geometry: every phase starts empty
+                memset(c->phaseState, 0, sizeof c->phaseState);
+                HIP_TRY(c, hipMemsetAsync(c->dPhaseCost, 0, (size_t)nTiles * 64 * sizeof(unsigned), c->phaseStream));
+                c->phaseTiles = nTiles;
+            }
+            phase = ((p->frameCount % 64) + 64) % 64;
+            if (c->phaseState[phase] == 1) {
+                const hipError_t q = hipEventQuery(c->evPhase[phase]);
+                (void)hipGetLastError();
+                if (q == hipSuccess) c->phaseState[phase] = 2;
+            }
+            // (a phase whose sort has not been SEEN complete keeps the average order chosen above: no stream ever waits for a sort)
+            if (c->phaseState[phase] == 2) sc.tileOrder = c->dPhaseOrder + (size_t)phase * nTiles;
+            sc.tileCost = c->dPhaseCost + (size_t)phase * nTiles;
+        }
+    }
     if (timed) HIP_TRY(c, hipEventRecord(c->evStart, s));
     HIP_TRY(c, rt_launch_render(f, sc, dColor, dPos, dNormal, counter, c->variant, s, countMode));
     if (timed) {
@@ -376,6 +434,16 @@ int launch(rt_context *c, const rt_params *p, float4 *dColor, float4 *dPos, uint
         c->timed = true;
     }
     HIP_TRY(c, hipEventRecord(mine->last, s));      // every launch, on every stream: rt_set_scene orders behind it
+    if (phase >= 0) {
+        // this frame's costs -> its phase's order, behind every launch that may still read that order (this one included), on
+        // the phase stream; the costs also join the all-phase average (dTileCost) that the periodic sort below works on
+        for (int i = 0; i < c->nFbStreams; i++) HIP_TRY(c, hipStreamWaitEvent(c->phaseStream, c->fbStreams[i].last, 0));
+        HIP_TRY(c, rt_launch_lpt_sort(c->dPhaseCost + (size_t)phase * nTiles, c->dPhaseSnap, c->dPhaseOrder + (size_t)phase * nTiles,
+                                      nTiles, c->phaseStream, c->dTileCost));
+        if (!c->evPhase[phase]) HIP_TRY(c, hipEventCreateWithFlags(&c->evPhase[phase], hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->evPhase[phase], c->phaseStream));
+        c->phaseState[phase] = 1;
+    }
     if (sortAfter) {
         // Re-sort on the first two frames of a geometry, then every fbPeriod-th.  Costs accumulate in between, so
         // the order follows each tile's AVERAGE cost over the period: with a free-running frameCount (which rotates
@@ -420,6 +488,7 @@ int rt_create(rt_context **out, int deviceId) {
     }
     if (const char *e = getenv("RT_DEBUG_PRED_CLASSES")) c->dbgWantCls = atoi(e) != 0;
     if (const char *e = getenv("RT_PRED_MIN_TILES")) c->predMinTiles = atoi(e);
+    if (const char *e = getenv("RT_PHASE_ORDER")) c->phaseOn = atoi(e) != 0;
     if (const char *e = getenv("RT_ST_GEOM")) {        // "Kcube,Kplan,NB": measurement override of the shadow-table geometry
         int kc = 0, kp = 0, nb = 0;
         if (sscanf(e, "%d,%d,%d", &kc, &kp, &nb) == 3 && kc >= 4 && kc <= 128 && kp >= 4 && kp <= 256 && nb >= 1 && nb <= 128)
@@ -440,6 +509,11 @@ int rt_destroy(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->phaseStream) { (void)hipStreamSynchronize(c->phaseStream); (void)hipStreamDestroy(c->phaseStream); }
+    for (int k = 0; k < 64; k++)
+        if (c->evPhase[k]) (void)hipEventDestroy(c->evPhase[k]);
+    for (void *b : {(void *)c->dPhaseCost, (void *)c->dPhaseOrder, (void *)c->dPhaseSnap})
+        if (b) (void)hipFree(b);
     for (int i = 0; i < rt_context::kMaxStreams; i++) {
         if (c->fbStreams[i].last) {
             (void)hipEventSynchronize(c->fbStreams[i].last);

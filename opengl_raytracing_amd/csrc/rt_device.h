@@ -77,7 +77,7 @@ void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, 
 // Heavy-first tile order predicted from the frame's own inputs (rt_predict_tiles_kernel): no history involved.
 hipError_t rt_launch_predict_order(const RtFrame &f, const RtDeviceScene &sc, int tilesX, int nTiles, unsigned *dSeg, int segStride,
                                    unsigned *dCursors, unsigned *dNextCursors, unsigned char *dCls, unsigned *dOrder, hipStream_t s);
-hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s);
+hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s, unsigned *dAccum = nullptr);
 hipError_t rt_launch_iota(unsigned *dOrder, int n, hipStream_t s);      // dOrder[i] = i (identity tile order)
 hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
                                  float blend, float jx, float jy, hipStream_t s);

@@ -1103,8 +1103,10 @@ void rt_packet_geometry(int nObj, int regionW, int regionH, int *bt, int *tile, 
 // bin is arbitrary -- this is a scheduling hint, never a data dependency.  Frames on other streams may
 // be updating `cost` while this runs, so every cost is read ONCE into `snap` and both passes bin the
 // snapshot: `order` is always a permutation of the tiles.  Costs are cleared for the next accumulation.
+// `accum` (optional): the costs read here are also added to a second cost buffer (the per-phase sorts of a free-running
+// frameCount feed the all-phase average this way, rt_abi.cpp).
 __global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict__ cost, unsigned *__restrict__ snap,
-                                                           unsigned *__restrict__ order, int nTiles) {
+                                                           unsigned *__restrict__ order, int nTiles, unsigned *__restrict__ accum) {
     __shared__ unsigned bins[256];
     __shared__ unsigned maxCost;
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
@@ -1114,6 +1116,7 @@ __global__ __launch_bounds__(1024) void rt_lpt_sort_kernel(unsigned *__restrict_
     for (int i = threadIdx.x; i < nTiles; i += 1024) {
         const unsigned c = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         snap[i] = c;
+        if (accum) atomicAdd(&accum[i], c);
         mx = max(mx, c);
     }
     atomicMax(&maxCost, mx);
@@ -1156,9 +1159,9 @@ hipError_t rt_launch_iota(unsigned *dOrder, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s) {
+hipError_t rt_launch_lpt_sort(unsigned *dCost, unsigned *dSnap, unsigned *dOrder, int nTiles, hipStream_t s, unsigned *dAccum) {
     if (nTiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_lpt_sort_kernel, dim3(1), dim3(1024), 0, s, dCost, dSnap, dOrder, nTiles);
+    hipLaunchKernelGGL(rt_lpt_sort_kernel, dim3(1), dim3(1024), 0, s, dCost, dSnap, dOrder, nTiles, dAccum);
     return hipGetLastError();
 }
 

@@ -495,7 +495,8 @@ __global__ __launch_bounds__(256) void rt_ssao_kernel(const float4 *__restrict__
         for (int r = 0; r < 4; r++) vw[r] = ((V[r] * px + V[4 + r] * py) + V[8 + r] * pz) + V[12 + r] * 1.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) of[r] = ((P[r] * vw[0] + P[4 + r] * vw[1]) + P[8 + r] * vw[2]) + P[12 + r] * vw[3];
-        float ox = of[0] / of[3], oy = of[1] / of[3];
+        float ox, oy;
+        rtf::div2(of[0], of[1], of[3], ox, oy);        // offset.xy / offset.w, correctly rounded (rt_fastmath.h)
         ox = ox * 0.5f + 0.5f;
         oy = oy * 0.5f + 0.5f;
         const float sampleDepth = depth[(size_t)ssao_nearest_repeat(oy, H) * W + ssao_nearest_repeat(ox, W)];
