@@ -124,18 +124,35 @@ __device__ __forceinline__ float rcp_sqrt(float x) {
 #endif
 }
 
-// Two correctly rounded quotients with one denominator (a0/b, a1/b: a perspective divide).  With y = RN(1/b) from the
-// reciprocal above: q = a*y is within an ulp of a/b, r = fma(-b, q, a) is the exact remainder, and RN(q + r*y) is the
-// correctly rounded quotient (Markstein's theorem) -- as long as nothing under- or overflows on the way: y and the
-// result normal numbers, |a| >= 2^-100 (below, the remainder's low bits fall under 2^-149).  9 issue slots + 5 compares
-// for the pair against 2 x 11 with two mode switches; everything else, a == 0 included, takes the IEEE sequences through
-// the wave-uniform branch.  tools/fastmath_exhaustive.hip: 2^34 random and structured (a, b) pairs, no mismatch while ok.
+// Correctly rounded quotients a/b that SHARE a reciprocal (a perspective divide, vec3 / float, a per-ray denominator).
+// With y = RN(1/b) from rcp_fast above: q = a*y is within an ulp of a/b, r = fma(-b, q, a) is the exact remainder, and
+// RN(q + r*y) is the correctly rounded quotient (Markstein's theorem) -- as long as nothing under- or overflows on the
+// way: y and the result normal numbers, |a| >= 2^-100 (below, the remainder's low bits fall under 2^-149).  a = +-0 is
+// exact as q = a*y itself (the corrected value would lose the sign of -0).  3 issue slots + 3 compares per quotient and 3
+// per reciprocal, against 11 with two mode switches for each IEEE division; callers OR the `ok` flags of a whole group of
+// divisions and redo the group with the IEEE sequences in a wave-uniform branch when any is false.
+// tools/fastmath_exhaustive.hip: 6 x 2^33 random, structured and boundary (a, b) pairs, no mismatch while ok.
 __device__ __forceinline__ float div_fast(float a, float b, float y, bool &ok) {
     const float q = a * y;
     const float r = __builtin_fmaf(-b, q, a);
     const float q1 = __builtin_fmaf(r, y, q);
-    ok = __builtin_amdgcn_classf(q1, CLS_NNORM | CLS_PNORM) & (__builtin_fabsf(a) >= 0x1p-100f);
-    return q1;
+    const bool zero = a == 0.0f;
+    ok = (__builtin_amdgcn_classf(q1, CLS_NNORM | CLS_PNORM) & (__builtin_fabsf(a) >= 0x1p-100f)) | zero;
+    return zero ? q : q1;
+}
+
+// vec3 / float (one reciprocal, three quotients), correctly rounded for every input.
+__device__ __forceinline__ void div3(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2) {
+#if RT_FASTMATH
+    bool oky, ok0, ok1, ok2;
+    const float y = rcp_fast(b, oky);
+    q0 = div_fast(a0, b, y, ok0);
+    q1 = div_fast(a1, b, y, ok1);
+    q2 = div_fast(a2, b, y, ok2);
+    if (!RT_FASTMATH_NOFB && __builtin_expect(__builtin_amdgcn_ballot_w64(!(oky & ok0 & ok1 & ok2)) != 0ull, 0)) { q0 = a0 / b; q1 = a1 / b; q2 = a2 / b; }
+#else
+    q0 = a0 / b; q1 = a1 / b; q2 = a2 / b;
+#endif
 }
 
 __device__ __forceinline__ void div2(float a0, float a1, float b, float &q0, float &q1) {

@@ -40,6 +40,8 @@ __device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y -
 __device__ __forceinline__ v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ v3 operator/(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+// the same through rt_fastmath.h's shared reciprocal (correctly rounded for every input; hot call sites)
+__device__ __forceinline__ v3 div3(v3 a, float s) { v3 r; rtf::div3(a.x, a.y, a.z, s, r.x, r.y, r.z); return r; }
 __device__ __forceinline__ v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ v3 splat(float s) { return V3(s, s, s); }
 // llvmpipe lowering: dot = (z*z + y*y) + x*x
@@ -299,8 +301,13 @@ __device__ __forceinline__ float fresnel_schlick(float cosTheta, float ior) {
     return r0 + (1.0f - r0) * pow5(1.0f - cosTheta);
 }
 
-// computePBR (:226-253)
-__device__ __forceinline__ v3 compute_pbr(const Mat &m, v3 N, v3 V, v3 L, v3 H, v3 radiance) {
+// computePBR (:226-253).  Its nine divisions (NDF, the two G factors, vec3 / float twice) are 99 of its ~190 VALU
+// instructions as IEEE sequences; FAST takes them through rt_fastmath.h's shared-reciprocal quotients (correctly rounded
+// while `ok`, which is OR-ed over all nine) and the caller redoes the call with the IEEE divisions when a wave has a lane
+// whose operands leave the fast range (a wave-uniform branch that C2..C5 never take: tools/gpu_fastmath_stats.py).
+constexpr float RCP_PI_F = 0x1.45f306p-2f;      // RN(1 / PI_F), PI_F being the float the shader's 3.14159265359 rounds to
+template <bool FAST>
+__device__ __forceinline__ v3 compute_pbr_t(const Mat &m, v3 N, v3 V, v3 L, v3 H, v3 radiance, bool &ok) {
     float alpha = m.roughness * m.roughness;
     float NdotH = fmaxf(dot(N, H), 0.0f);
     // Mesa's NIR rewrites x*(a2-1)+1 as lerp(1, a2, x) = (1-x) + a2*x and PI*(i*i) as (PI*i)*i;
@@ -308,21 +315,64 @@ __device__ __forceinline__ v3 compute_pbr(const Mat &m, v3 N, v3 V, v3 L, v3 H, 
     // form differs by up to 4e-4 rel in NDF.
     float nh2 = NdotH * NdotH;
     float inner = (1.0f - nh2) + (alpha * alpha) * nh2;
-    float NDF = alpha * alpha / ((PI_F * inner) * inner);
+    const float ndfDen = (PI_F * inner) * inner;
     float rp1 = m.roughness + 1.0f;
     float k = (rp1 * rp1) / 8.0f;
     float NdotV = fmaxf(dot(N, V), 0.0f), NdotL = fmaxf(dot(N, L), 0.0f);
-    float G = NdotV / (NdotV * (1.0f - k) + k);
-    G *= NdotL / (NdotL * (1.0f - k) + k);
+    const float gvDen = NdotV * (1.0f - k) + k, glDen = NdotL * (1.0f - k) + k;
+    float NDF, G;
+    ok = true;
+    if constexpr (FAST) {
+        bool o0, o1, o2, q0, q1, q2;
+        const float y0 = rtf::rcp_fast(ndfDen, o0), y1 = rtf::rcp_fast(gvDen, o1), y2 = rtf::rcp_fast(glDen, o2);
+        NDF = rtf::div_fast(alpha * alpha, ndfDen, y0, q0);
+        G = rtf::div_fast(NdotV, gvDen, y1, q1);
+        G *= rtf::div_fast(NdotL, glDen, y2, q2);
+        ok = o0 & o1 & o2 & q0 & q1 & q2;
+    } else {
+        NDF = alpha * alpha / ndfDen;
+        G = NdotV / gvDen;
+        G *= NdotL / glDen;
+    }
     v3 F0 = mix_strict(splat(0.04f), m.albedo, m.metallic);
     float p5 = pow5(1.0f - fmaxf(dot(H, V), 0.0f));
     v3 F = F0 + (splat(1.0f) - F0) * p5;
     v3 numerator = F * (NDF * G);
     float denominator = 4.0f * NdotV * NdotL;
-    v3 specular = numerator / fmaxf(denominator, 0.001f);
+    const float specDen = fmaxf(denominator, 0.001f);
     v3 kD = (splat(1.0f) - F) * (1.0f - m.metallic);
-    v3 diffuse = (kD * m.albedo) / PI_F;
+    const v3 dnum = kD * m.albedo;
+    v3 specular, diffuse;
+    if constexpr (FAST) {
+        bool o3, s0, s1, s2, d0, d1, d2;
+        const float y3 = rtf::rcp_fast(specDen, o3);
+        specular = V3(rtf::div_fast(numerator.x, specDen, y3, s0), rtf::div_fast(numerator.y, specDen, y3, s1), rtf::div_fast(numerator.z, specDen, y3, s2));
+        diffuse = V3(rtf::div_fast(dnum.x, PI_F, RCP_PI_F, d0), rtf::div_fast(dnum.y, PI_F, RCP_PI_F, d1), rtf::div_fast(dnum.z, PI_F, RCP_PI_F, d2));
+        ok = ok & o3 & s0 & s1 & s2 & d0 & d1 & d2;
+    } else {
+        specular = numerator / specDen;
+        diffuse = dnum / PI_F;
+    }
     return ((diffuse + specular) * radiance) * NdotL;
+}
+
+#ifndef RT_FAST_DIV
+#define RT_FAST_DIV 1           // 0: every general division of the path by the compiler's IEEE sequence
+#endif
+// `live`: lanes whose result is used (the packet kernel calls this with the whole wave; a dead lane's stale or NaN operands
+// must not send the wave through the IEEE instantiation).  FASTDIV is a profile constant of the packet kernel: measured,
+// bit-identical, C4 4.78 -> 4.66 ms and C5 25.3 -> 24.9 ms with it, but C2 0.347 -> 0.367 and C3 3.39 -> 3.44 (the LIGHT
+// profiles' register allocation, not the fallback: masking it with `live` changed nothing) -- so the many-object profiles use it.
+template <bool FASTDIV = false>
+__device__ __forceinline__ v3 compute_pbr(const Mat &m, v3 N, v3 V, v3 L, v3 H, v3 radiance, bool live = true) {
+    bool ok;
+    if constexpr (FASTDIV && RT_FAST_DIV) {
+        v3 r = compute_pbr_t<true>(m, N, V, L, H, radiance, ok);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(live && !ok) != 0ull, 0)) r = compute_pbr_t<false>(m, N, V, L, H, radiance, ok);
+        return r;
+    } else {
+        return compute_pbr_t<false>(m, N, V, L, H, radiance, ok);
+    }
 }
 
 // cosineWeightedHemisphere (:291-308) with the per-depth local direction h precomputed on
@@ -641,7 +691,7 @@ __global__ RT_V0_BOUNDS void rt_render_kernel(const RtFrame f, const RtDeviceSce
             float cp = fminf(fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)) * 0.95f + dw, 0.99f);
             float rnd = random2((float)(gx + (unsigned)depth), (float)(gy + (unsigned)depth));
             if (rnd > cp) break;
-            throughput = throughput / cp;
+            throughput = div3(throughput, cp);
         }
         float F = fresnel_schlick(fmaxf(dot(V, N), 0.0f), m.ior);
         if (m.diffuseStrength > 0.0f) {          // :555-567

@@ -447,6 +447,60 @@ __global__ __launch_bounds__(256) void rt_ssao_depth_kernel(const float4 *__rest
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) depth[k] = position[k].z;
 }
 
+#ifndef RT_SSAO_FASTDIV
+#define RT_SSAO_FASTDIV 1       // 0 = the compiler's IEEE divisions in the sample loop
+#endif
+
+// ssaoFs.glsl:27-44, the 64 kernel samples of one pixel.  FAST: divisions by rt_fastmath.h's fast paths; returns NaN when
+// any of them left its exact range (the caller then takes the IEEE instantiation).  The true sum is never NaN-free-checked:
+// a genuine NaN (NaN G-buffer) also sends the wave through the IEEE loop, which reproduces it.
+template <bool FAST>
+__device__ __forceinline__ float ssao_samples(const RtSsaoArgs &a, const float *__restrict__ depth, const float4 fp, float nx, float ny, float nz,
+                                              float tx, float ty, float tz, float bx, float by, float bz, int W, int H) {
+    float occlusion = 0.0f;
+    bool bad = false;
+    const float *V = a.view, *P = a.projection;
+#pragma unroll RT_SSAO_UNROLL
+    for (int k = 0; k < 64; k++) {
+        const float s0 = a.samples[k][0], s1 = a.samples[k][1], s2 = a.samples[k][2];
+        float px = (tx * s0 + bx * s1) + nx * s2, py = (ty * s0 + by * s1) + ny * s2, pz = (tz * s0 + bz * s1) + nz * s2;
+        px = fp.x + px * 0.5f; py = fp.y + py * 0.5f; pz = fp.z + pz * 0.5f;
+        float vw[4], of[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) vw[r] = ((V[r] * px + V[4 + r] * py) + V[8 + r] * pz) + V[12 + r] * 1.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) of[r] = ((P[r] * vw[0] + P[4 + r] * vw[1]) + P[8 + r] * vw[2]) + P[12 + r] * vw[3];
+        float ox, oy;
+        if constexpr (FAST) {           // offset.xy / offset.w: one refined reciprocal, two Markstein corrections
+            bool oky, ok0, ok1;
+            const float y = rtf::rcp_fast(of[3], oky);
+            ox = rtf::div_fast(of[0], of[3], y, ok0);
+            oy = rtf::div_fast(of[1], of[3], y, ok1);
+            bad |= !(oky & ok0 & ok1);
+        } else {
+            ox = of[0] / of[3]; oy = of[1] / of[3];
+        }
+        ox = ox * 0.5f + 0.5f;
+        oy = oy * 0.5f + 0.5f;
+        const float sampleDepth = depth[(size_t)ssao_nearest_repeat(oy, H) * W + ssao_nearest_repeat(ox, W)];
+        const float adz = fabsf(fp.z - sampleDepth);
+        float x;
+        if constexpr (FAST) {           // 0.5 / |dz| = RN(1 / |dz|) * 0.5: the halving is exact while reciprocal and product are normal
+            bool okr;
+            x = rtf::rcp_fast(adz, okr) * 0.5f;
+            const bool zero = adz == 0.0f;        // equal depths (flat regions, the pixel itself): 0.5 / 0 = +inf, no reason to leave the fast loop
+            x = zero ? __builtin_huge_valf() : x;
+            bad |= !((okr & (adz <= 0x1p125f)) | zero);
+        } else {
+            x = 0.5f / adz;
+        }
+        const float tt = fminf(fmaxf(x, 0.0f), 1.0f);
+        const float rangeCheck = tt * (tt * (3.0f - 2.0f * tt));
+        occlusion += (sampleDepth >= pz + 0.025f ? 1.0f : 0.0f) * rangeCheck;
+    }
+    return (FAST && bad) ? __builtin_nanf("") : occlusion;
+}
+
 __global__ __launch_bounds__(256) void rt_ssao_kernel(const float4 *__restrict__ position, const uint2 *__restrict__ normal,
                                                       const float *__restrict__ depth, float *__restrict__ out, const RtSsaoArgs a) {
     // 256 threads = 4 waves, each an 8x8 tile of a 32x8 block
@@ -483,32 +537,20 @@ __global__ __launch_bounds__(256) void rt_ssao_kernel(const float4 *__restrict__
     float tx, ty, tz;
     ssao_nrm3(rx - nx * d, ry - ny * d, rz - nz * d, tx, ty, tz);
     const float bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;
-    float occlusion = 0.0f;
-    const float *V = a.view, *P = a.projection;
-#pragma unroll RT_SSAO_UNROLL
-    for (int k = 0; k < 64; k++) {
-        const float s0 = a.samples[k][0], s1 = a.samples[k][1], s2 = a.samples[k][2];
-        float px = (tx * s0 + bx * s1) + nx * s2, py = (ty * s0 + by * s1) + ny * s2, pz = (tz * s0 + bz * s1) + nz * s2;
-        px = fp.x + px * 0.5f; py = fp.y + py * 0.5f; pz = fp.z + pz * 0.5f;
-        float vw[4], of[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) vw[r] = ((V[r] * px + V[4 + r] * py) + V[8 + r] * pz) + V[12 + r] * 1.0f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) of[r] = ((P[r] * vw[0] + P[4 + r] * vw[1]) + P[8 + r] * vw[2]) + P[12 + r] * vw[3];
-        float ox, oy;
-        rtf::div2(of[0], of[1], of[3], ox, oy);        // offset.xy / offset.w, correctly rounded (rt_fastmath.h)
-        ox = ox * 0.5f + 0.5f;
-        oy = oy * 0.5f + 0.5f;
-        const float sampleDepth = depth[(size_t)ssao_nearest_repeat(oy, H) * W + ssao_nearest_repeat(ox, W)];
-        // 0.5 / |dz| = RN(1 / |dz|) * 0.5: halving is exact while reciprocal and product are normal numbers (|dz| in [2^-126, 2^125]),
-        // and rtf::rcp is the correctly rounded reciprocal without the compiler's 11-instruction division (rt_fastmath.h); any
-        // other |dz| -- 0, denormal, huge, NaN -- takes the IEEE division (wave-uniform branch, never taken on real G-buffers)
-        const float adz = fabsf(fp.z - sampleDepth);
-        float x = rtf::rcp(adz) * 0.5f;
-        if (__builtin_amdgcn_ballot_w64(!((adz >= 0x1p-126f) & (adz <= 0x1p125f))) != 0ull) x = 0.5f / adz;
-        const float tt = fminf(fmaxf(x, 0.0f), 1.0f);
-        const float rangeCheck = tt * (tt * (3.0f - 2.0f * tt));
-        occlusion += (sampleDepth >= pz + 0.025f ? 1.0f : 0.0f) * rangeCheck;
+    // The three divisions per sample (offset.xy / offset.w, 0.5 / |dz|) without the compiler's 11-instruction IEEE sequences
+    // (rt_fastmath.h: correctly rounded for operands in the ordinary exponent range, each with an `ok` flag).  The sample loop
+    // stays BRANCH-FREE -- a wave-uniform fallback branch per sample keeps the unrolled iterations' depth gathers from
+    // overlapping (measured: 398 -> 449 us @1080p with it, i.e. slower than the IEEE divisions) -- so the flags are only
+    // OR-ed, and a wave in which any lane's any sample left the fast range redoes its 64 samples with the IEEE divisions.
+    // (a wave holding a pixel without geometry -- zero normal, NaN basis: the sky -- goes to the IEEE loop directly)
+    const float chk = ((tx + ty) + tz) + ((bx + by) + bz) + ((fp.x + fp.y) + fp.z);
+    float occlusion;
+    if (RT_SSAO_FASTDIV != 0 && __builtin_amdgcn_ballot_w64(!(fabsf(chk) < __builtin_huge_valf())) == 0ull) {
+        occlusion = ssao_samples<true>(a, depth, fp, nx, ny, nz, tx, ty, tz, bx, by, bz, W, H);
+        if (__builtin_amdgcn_ballot_w64(occlusion != occlusion) != 0ull)
+            occlusion = ssao_samples<false>(a, depth, fp, nx, ny, nz, tx, ty, tz, bx, by, bz, W, H);
+    } else {
+        occlusion = ssao_samples<false>(a, depth, fp, nx, ny, nz, tx, ty, tz, bx, by, bz, W, H);
     }
     out[(size_t)j * W + i] = 1.0f - occlusion / 64.0f;
 }

@@ -7,6 +7,8 @@
 #define RT_FASTMATH_NO_FALLBACK 1      // test the fast paths alone: report where they need the fallback
 #include "../opengl_raytracing_amd/csrc/rt_fastmath.h"
 __device__ __forceinline__ bool same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+// signed zeros distinguished (a quotient's -0 must stay -0)
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
 __global__ void check(unsigned long long *out) {
     const unsigned base = (blockIdx.x * 256u + threadIdx.x) * 256u;
     unsigned long long bad[4] = {0, 0, 0, 0};
@@ -32,7 +34,8 @@ __global__ void check(unsigned long long *out) {
 }
 // rtf::div2's fast path against the IEEE division on (a, b) pairs: mode 0 = random bit patterns, 1 = random mantissas with
 // exponents within +-40 of 1.0 (the perspective divide's range), 2 = structured mantissas (all ones / zeros / +-1 ulp of them)
-// with random exponents, 3 = a = RN(q*b) +- few ulps for random q, b (quotients at and next to rounding boundaries).
+// with random exponents, 3 = a = RN(q*b) +- few ulps for random q, b (quotients at and next to rounding boundaries),
+// 4 = numerators +-0, denormal, 2^-107, 2^-100, 2^123 against denominators of every ordinary exponent.
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     z += 0x9e3779b97f4a7c15ull; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31);
 }
@@ -56,6 +59,13 @@ __global__ void check_div(unsigned long long *out, int mode, unsigned long long 
             uc = (uc & 0xff800000u) | structured_mant((unsigned)(h2 >> 20));
         }
         float a = __uint_as_float(ua), b = __uint_as_float(ub), c = __uint_as_float(uc);
+        if (mode == 4) {                     // signed zeros, tiny and huge numerators against ordinary denominators
+            const unsigned sel = (unsigned)(h2 >> 50) % 6u;
+            ua = sel == 0 ? 0u : sel == 1 ? 0x80000000u : sel == 2 ? (ua & 0x807fffffu) : sel == 3 ? ((ua & 0x807fffffu) | (20u << 23)) : sel == 4 ? ((ua & 0x807fffffu) | (27u << 23)) : ((ua & 0x807fffffu) | (250u << 23));
+            ub = (ub & 0x807fffffu) | ((60u + ((ub >> 23) & 0xffu) % 135u) << 23);
+            a = __uint_as_float(ua); b = __uint_as_float(ub);
+            c = __uint_as_float(ua ^ 0x80000000u);
+        }
         if (mode == 3) {
             ub = (ub & 0x807fffffu) | ((100u + ((ub >> 23) & 0xffu) % 55u) << 23);
             ua = (ua & 0x807fffffu) | ((100u + ((ua >> 23) & 0xffu) % 55u) << 23);
@@ -66,11 +76,11 @@ __global__ void check_div(unsigned long long *out, int mode, unsigned long long 
         bool oky, ok0, ok1;
         const float y = rtf::rcp_fast(b, oky);
         const float q0 = rtf::div_fast(a, b, y, ok0), q1 = rtf::div_fast(c, b, y, ok1);
-        bad += (oky && ok0 && !same(q0, a / b)) + (oky && ok1 && !same(q1, c / b));
+        bad += (oky && ok0 && !same_bits(q0, a / b)) + (oky && ok1 && !same_bits(q1, c / b));
         fb += !(oky && ok0 && ok1);
         float f0, f1;
         rtf::div2(a, c, b, f0, f1);
-        full += !same(f0, a / b) + !same(f1, c / b);
+        full += !same_bits(f0, a / b) + !same_bits(f1, c / b);
     }
     if (bad) atomicAdd(&out[0], bad);
     if (fb) atomicAdd(&out[1], fb);
@@ -80,7 +90,7 @@ static int run_div() {
     unsigned long long *d, h[3];
     (void)hipMalloc(&d, sizeof h);
     int rc = 0;
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         (void)hipMemset(d, 0, sizeof h);
         const int launches = (mode == 1 || mode == 3) ? 2 : 1;
         for (int l = 0; l < launches; l++) check_div<<<65536, 256>>>(d, mode, 0x1234567ull * (mode + 1) + 0x9e3779b97f4a7c15ull * l);
