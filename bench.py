@@ -39,7 +39,9 @@ Rank 0 prints ONE JSON line.  What the fields mean (VERDICT r1 asked for a recor
   `free_running_first_period` the first 64 new frames (all-phase average order).  Frames of >= 49 152 tiles without any
   measured order run in an order PREDICTED from their own inputs (rt_predict_tiles_kernel).  `cold_frame_ms` = new
   steady-state frames one at a time with a device sync in between (nothing overlaps; host launch + sync included);
-  `raster_order_ms` = the scheduler switched off.
+  `raster_order_ms` = the scheduler switched off.  `scene_update_every_frame_ms` = the headline frame with rt_set_scene of
+  CHANGED bytes in front of every frame (scene compile + shadow-table build; identical bytes, which is
+  what the reference re-uploads while nothing is edited, are a no-op).
 * `pipelined` = the headline frames with two in flight on two streams (the ABI is asynchronous): frame k's tail
   overlaps frame k+1's head.  Throughput, not latency.
 * `cpu_baseline` = the oracle port timed on this box's host cores; `cpu_baseline_reference` = the reference's own
@@ -243,6 +245,25 @@ def measure_single(cfg, steps, warmup, variant, dev_index, with_modes=True):
             lat.append((time.perf_counter() - c0) * 1e3)
         res["cold_frame_ms"] = round(float(np.mean(lat)), 4)
         res["cold_frame_rays_reference_mean"] = int(np.mean(cold_rays))
+        # (2b) the scene CHANGES every frame (an object dragged in the editor): rt_set_scene with new bytes -- staging copy, scene
+        #      compile and the shadow-table build -- in front of every frame (on the context's stream,
+        #      ordered behind the previous frame and in front of the next by events)
+        moved = scenes.make_scene(cfg, host.generate_aabb)
+        moved.objects["position"][0, 0] += 0.125
+        host.generate_aabb(moved.objects)
+        pair = [moved, sc]
+        n_dyn = max(8, min(steps, 32))
+        for k in range(4):
+            rt.set_scene(pair[k & 1].objects, pair[k & 1].lights)
+            render(base)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_dyn):
+            rt.set_scene(pair[k & 1].objects, pair[k & 1].lights)
+            render(base)
+        torch.cuda.synchronize()
+        res["scene_update_every_frame_ms"] = round((time.perf_counter() - t0) / n_dyn * 1e3, 4)
+        rt.set_scene(sc.objects, sc.lights)
         # (3) scheduler off: raster tile order, the headline frame
         rt.set_variant((variant & 0xff) | 0x100)
         for _ in range(2):
@@ -289,7 +310,8 @@ def single_record(cfg, r, steps, warmup, src_hash):
            "step_ms_device": round(r["step_ms_dev"], 4), "frame_ms": r["frame_ms"]}
     # the roofline's duration is the timed region's own (the one `value` is computed from), by HIP events on the launch stream
     out.update(roofline_record(cfg, sc, n_px, r["rays_ref"], r["step_ms_dev"], load_counters(cfg), src_hash))
-    for k in ("free_running", "free_running_first_period", "cold_frame_ms", "cold_frame_rays_reference_mean", "raster_order_ms", "pipelined"):
+    for k in ("free_running", "free_running_first_period", "cold_frame_ms", "cold_frame_rays_reference_mean", "scene_update_every_frame_ms",
+              "raster_order_ms", "pipelined"):
         if k in r:
             out[k] = r[k]
     return out

@@ -86,6 +86,7 @@ struct rt_context {
     size_t capShadowTab = 0;
     bool shadowTabValid = false;
     std::vector<uint8_t> lastScene;            // the bytes of the current scene (objects, then lights): an identical re-upload is a no-op
+    bool stOnePhase = false;                   // RT_ST_BUILD=full: the one-phase builder (every object in every cell; comparison builds only)
     RtShadowTabGeom stGeomSmall = {48, 96, 32}, stGeomLarge = {32, 64, 32};      // <= 32 objects / more (RT_ST_GEOM overrides both); measured: DESIGN.md
     // Scheduler (packet kernel).  schedMode 2 (default): tiles run longest-first by their MEASURED cost over the last frames of the
     // same window geometry (the feedback of rounds 1-2); while no measured order exists yet, frames of >= predMinTiles tiles run in
@@ -489,6 +490,7 @@ int rt_create(rt_context **out, int deviceId) {
     if (const char *e = getenv("RT_DEBUG_PRED_CLASSES")) c->dbgWantCls = atoi(e) != 0;
     if (const char *e = getenv("RT_PRED_MIN_TILES")) c->predMinTiles = atoi(e);
     if (const char *e = getenv("RT_PHASE_ORDER")) c->phaseOn = atoi(e) != 0;
+    if (const char *e = getenv("RT_ST_BUILD")) c->stOnePhase = strcmp(e, "full") == 0;
     if (const char *e = getenv("RT_ST_GEOM")) {        // "Kcube,Kplan,NB": measurement override of the shadow-table geometry
         int kc = 0, kp = 0, nb = 0;
         if (sscanf(e, "%d,%d,%d", &kc, &kp, &nb) == 3 && kc >= 4 && kc <= 128 && kp >= 4 && kp <= 256 && nb >= 1 && nb <= 128)
@@ -590,7 +592,7 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     if (nObj > 0 && nLt > 0 && nObj <= RT_ST_MAX_OBJECTS && nLt <= RT_ST_MAX_LIGHTS) {
         const RtShadowTabGeom &g = nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
         if ((rc = ensure(c, &c->dShadowTab, &c->capShadowTab, rt_shadowtab_dwords(g, nObj, nLt)))) return rc;
-        HIP_TRY(c, rt_launch_shadow_tables(c->dCompiled, nObj, nLt, c->dShadowTab, g, c->stream));
+        HIP_TRY(c, rt_launch_shadow_tables(c->dCompiled, nObj, nLt, c->dShadowTab, g, c->stream, c->stOnePhase));
         c->shadowTabValid = true;
     }
     HIP_TRY(c, hipEventRecord(c->evScene, c->stream));   // foreign streams order behind this (rt_render_to)
@@ -797,7 +799,7 @@ int rt_debug_shadow_tables(rt_context *c, uint32_t *out, size_t capDwords, size_
     if (wordsPerCell) *wordsPerCell = 0;
     if (!c->shadowTabValid) return RT_OK;
     const RtShadowTabGeom &g = c->nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
-    const size_t n = rt_shadowtab_dwords(g, c->nObj, c->nLt);
+    const size_t n = rt_shadowtab_table_dwords(g, c->nObj, c->nLt);      // (the builder's scratch behind the tables is not part of them)
     *nDwords = n;
     if (wordsPerCell) *wordsPerCell = rt_shadowtab_words(c->nObj);
     if (!out) return RT_OK;

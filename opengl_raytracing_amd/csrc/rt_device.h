@@ -51,11 +51,21 @@ static inline int rt_shadowtab_words(int nObj) { return nObj <= 32 ? 1 : (nObj <
 // Table geometry: cube-map cells per face edge (point / area lights), grid cells per axis (directional), bins; and the
 // buffer size in dwords that holds any mix of light types.
 struct RtShadowTabGeom { int Kcube, Kplan, NB; };
-static inline size_t rt_shadowtab_dwords(const RtShadowTabGeom &g, int nObj, int nLt) {
+// direction cells of one light (the builder's phase-1 supersets, stored behind the tables)
+static inline size_t rt_shadowtab_dir_cells(const RtShadowTabGeom &g) {
+    const size_t cube = (size_t)6 * g.Kcube * g.Kcube, plan = (size_t)g.Kplan * g.Kplan;
+    return cube > plan ? cube : plan;
+}
+// dwords of headers + cells (what the render kernel reads, and rt_debug_shadow_tables returns)
+static inline size_t rt_shadowtab_table_dwords(const RtShadowTabGeom &g, int nObj, int nLt) {
     const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
     return (size_t)nLt * RT_ST_HDR_F4 * 4 + (size_t)nLt * (cube > plan ? cube : plan) * rt_shadowtab_words(nObj) + 4;
 }
-hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s);
+// ... + the builder's scratch
+static inline size_t rt_shadowtab_dwords(const RtShadowTabGeom &g, int nObj, int nLt) {
+    return rt_shadowtab_table_dwords(g, nObj, nLt) + (size_t)nLt * rt_shadowtab_dir_cells(g) * rt_shadowtab_words(nObj);
+}
+hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s, bool onePhase = false);
 
 #define RT_PCF_TAB_N 16      // PCF samples tabulated per directional light (UI range of pcfSamples is 1..16)
 // float4 count of the whole compiled buffer: the staged part (rt_compiled_f4) + per light RT_PCF_TAB_N x 2 float4

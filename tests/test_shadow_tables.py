@@ -219,3 +219,44 @@ def test_tables_cover_every_hit_of_fuzzed_scenes(tracer, host):
         if st:
             total += st["hits"]
     assert total > 0
+
+
+def test_two_phase_build_equals_the_one_phase_build(host):
+    """rt_set_scene builds the tables in two phases (every object once per DIRECTION cell, then the per-bin tests for the objects
+    that survived: rt_shadowtab.inc); RT_ST_BUILD=full keeps the one-phase builder that tests every object in every cell.  The
+    tests are monotone along the bin axis, so both must produce the same tables: headers identical, every cell of the two-phase
+    table a subset of the one-phase cell (that alone keeps it rigorous only together with the monotonicity argument, hence:) and
+    equal in all but a vanishing fraction of cells (fp32 borderline cases of the monotonicity)."""
+    import os
+    from test_gpu_parity import _fuzz_scene
+    todo = [scenes.make_scene(cfg, host.generate_aabb) for cfg in (2, 3, 4, 5)]
+    todo += [sc for sc in (_fuzz_scene(seed) for seed in range(0, 24)) if 0 < len(sc.objects) <= 256 and len(sc.lights) > 0]
+    cells = diff = 0
+    for sc in todo:
+        with host.RayTracer(0) as two:
+            two.load(sc)
+            t2, nw = two.shadow_tables()
+        os.environ["RT_ST_BUILD"] = "full"
+        try:
+            with host.RayTracer(0) as one:
+                one.load(sc)
+                t1, nw1 = one.shadow_tables()
+        finally:
+            del os.environ["RT_ST_BUILD"]
+        if t2 is None:
+            assert t1 is None
+            continue
+        assert nw == nw1 and t1.shape == t2.shape
+        nh = len(sc.lights) * 6 * 4
+        assert np.array_equal(t1[:nh], t2[:nh]), f"{sc.name}: headers differ"
+        for li in range(len(sc.lights)):         # each light's cells: [base, base + nCells * nw) dwords (the rest of the buffer is unused)
+            hdr = t1[li * 24:(li + 1) * 24]
+            kind, base, n_cells = int(hdr[0]), int(hdr[1]), int(hdr[11])        # header ints are stored as raw bits
+            if kind == 0:
+                continue
+            a, b = t1[base:base + n_cells * nw], t2[base:base + n_cells * nw]
+            assert not (b & ~a).any(), f"{sc.name} light {li}: the two-phase table lists an object the one-phase table does not"
+            cells += a.size
+            diff += int((a != b).sum())
+    print(f"two-phase vs one-phase: {diff} of {cells} cell words differ")
+    assert diff <= cells * 1e-5
