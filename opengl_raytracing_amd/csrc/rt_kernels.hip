@@ -1053,11 +1053,11 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s, bool onePhase) {
     if (nLt <= 0 || nObj <= 0 || nObj > RT_ST_MAX_OBJECTS || nLt > RT_ST_MAX_LIGHTS) return hipSuccess;
     const int NW = rt_shadowtab_words(nObj);
-    hipLaunchKernelGGL(rt_shadowtab_headers_kernel, dim3(1), dim3(64), 0, s, dCompiled, nObj, nLt, (float4 *)dTab, g.Kcube, g.Kplan,
-                       g.NB, NW, RT_ST_NMAX);
     const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
+    hipLaunchKernelGGL(rt_shadowtab_headers_kernel, dim3((unsigned)nLt), dim3(64), 0, s, dCompiled, nObj, nLt, (float4 *)dTab, g.Kcube, g.Kplan,
+                       g.NB, NW, RT_ST_NMAX, (unsigned)(cube > plan ? cube : plan));
     const size_t maxCells = cube > plan ? cube : plan, dirCells = rt_shadowtab_dir_cells(g), dirBase = rt_shadowtab_table_dwords(g, nObj, nLt);
-    const dim3 gridCells((unsigned)((maxCells + 255) / 256), (unsigned)nLt), gridDir((unsigned)((dirCells + 255) / 256), (unsigned)nLt);
+    const dim3 gridCells((unsigned)((maxCells + 255) / 256), (unsigned)nLt), gridDir((unsigned)((dirCells + 255) / 256), (unsigned)nLt, (unsigned)NW);
     if (onePhase) {
         hipLaunchKernelGGL(rt_shadowtab_build_kernel<0>, gridCells, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, dirBase, dirCells);
     } else {      // every object per direction cell once, then the per-bin tests for the survivors (rt_shadowtab.inc)
