@@ -375,13 +375,16 @@ def peer_store_child(args):
     print(json.dumps(out), flush=True)
 
 
-def run_peer_store_child(world, cfg, extra, steps, warmup, timeout_s=300):
-    """Rank 0: the peer-store measurement in a child process (own HIP contexts on all N devices) under a timeout."""
+def run_peer_store_child(world, cfg, extra, steps, warmup, timeout_s=300, devices=None):
+    """Rank 0: the peer-store measurement in a child process (own HIP contexts on all N devices) under a timeout.
+    devices: explicit list (the one-GPU rehearsal passes [0] * N: control flow only)."""
     import subprocess
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     cmd = [sys.executable, os.path.abspath(__file__), "--peer-store-child", str(world), "--config", str(cfg),
            "--extra-configs", ",".join(str(c) for c in extra) or "none", "--steps", str(steps), "--warmup", str(warmup)]
+    if devices:
+        cmd += ["--peer-store-devices", ",".join(str(d) for d in devices)]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -751,7 +754,7 @@ def main():
         k = max(3, min(args.steps, 10))
         extras[f"c{c}"] = run_config(c, k, 2, autotune=False)
     peer = None
-    if world > 1 and not args.no_peer_store and not args.rehearse_on_one_gpu:
+    if world > 1 and not args.no_peer_store:
         # the other ranks wait on the rendezvous store (host side): an RCCL barrier would spin on their GPUs meanwhile
         torch.cuda.synchronize()
         dist.barrier()
@@ -761,7 +764,8 @@ def main():
         except Exception:
             pass
         if rank == 0:
-            peer = run_peer_store_child(world, args.config, extra, args.steps, args.warmup)
+            peer = run_peer_store_child(world, args.config, extra, args.steps, args.warmup,
+                                        devices=[0] * world if args.rehearse_on_one_gpu else None)
             if store is not None:
                 store.set("bench_peer_store_done", "1")
         elif store is not None:
