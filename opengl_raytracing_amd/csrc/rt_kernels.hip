@@ -100,6 +100,7 @@ struct SceneLds {
     bool compact = false;
     bool boundsLds = true;      // packet kernel profile: the cull passes' per-lane AABB reads come from LDS (else from the global copy)
     bool wedge = false;         // packet kernel profile: convergent-packet cull of point / area light shadow rays
+    int straight = 0;           // packet kernel profile: which candidate loops use the predicate-algebra tests (rt_packet.inc RT_PK_STRAIGHT)
     bool split = false;         // packet kernel profile: octant-split culling of sign-straddling packets
     bool keepAabb = true;       // packet kernel profile: chunk 0's AABB lives in the lane's VGPRs (else re-read from LDS per cull pass)
     int hotStride = RT_HOT_F4, matF4Base = 0;
@@ -764,6 +765,7 @@ void rt_render_packet_kernel(const RtFrame f, const RtDeviceScene dsc, float4 *_
     sc.compact = COMPACT;
     sc.keepAabb = PROFILE::keepAabb;
     sc.boundsLds = PROFILE::boundsLds;
+    sc.straight = PROFILE::straight;
     sc.split = PROFILE::split;
     sc.wedge = PROFILE::wedge;
     sc.hotStride = COMPACT ? 2 : RT_HOT_F4;
