@@ -143,8 +143,149 @@ __global__ __launch_bounds__(256) void rt_taa_resolve_kernel(const float4 *__res
                                          resolve(his.z, cur.z, mn.z, mx.z), 1.0f);
 }
 
+// The same resolve with a REGISTER WINDOW: one lane per column walks RT_TAA_ROWS consecutive rows and keeps three rows x three
+// columns of `current` and of `history` in registers, so a pixel costs 6 x (ROWS + 2) / ROWS texel loads instead of 17.  The
+// one-texel-per-lane kernel above is bound by the L1 pipeline rather than by HBM: its 17 loads per pixel are 288 B of L1 traffic
+// against 56 B of compulsory bytes -- with the neighbourhood and bilinear loads stubbed out (timing experiment) it runs 20.3 us at
+// 1080p against 28.7.  Arithmetic per pixel is the kernel above's, operation for operation; what changes is where a tap's texel
+// comes from: the bilinear taps of `current` (REPEAT) are taken from the window when they fall inside it and inside the image (the
+// jitter is a fraction of a texel: taaFs.glsl:23 with ForwardShadingPipeline.cpp:241-242) and loaded as before otherwise; the
+// history taps (CLAMP_TO_EDGE) are window texels whenever floor(u * W - 0.5) is i - 1 or i, which fp32 guarantees for every pixel
+// centre; the 3x3 box is the window itself (texelFetch: 0 outside the image).
+// Measured, bit-identical (tools/bench_taa.py, same run): 1080p 28.8 -> 27.1 us, 4K 135 -> 118 us, 8K 498 -> 427 us.  Two
+// further forms were written, pass the same tests and were NOT kept: each lane loading only its own column and taking the
+// neighbouring columns from the adjacent lanes (DPP wave shifts), one row ahead of its use -- a quarter of the loads again, but
+// 136 VGPRs / 3 waves and two loads in flight per wave: 36 / 139 / 531 us; and both surfaces staged as 64 x 8..32 pixel tiles in
+// LDS (1.2 loads per pixel and surface, taps from LDS): 30 / 118 / 415 us at best.
+#ifndef RT_TAA_ROWS
+#define RT_TAA_ROWS 8
+#endif
+__global__ __launch_bounds__(256) void rt_taa_resolve_rows_kernel(const float4 *__restrict__ current, const float4 *__restrict__ history,
+                                                                  const uint2 *__restrict__ normal, float4 *__restrict__ out, int W, int H,
+                                                                  float blendFactor, float jitterX, float jitterY) {
+    constexpr int R = RT_TAA_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int j0 = (blockIdx.y * 4 + wave) * R;
+    if (i >= W || j0 >= H) return;
+    const int xl = clampi(i - 1, W), xr = clampi(i + 1, W);
+    rgb c[3][3], h[3][3];            // [row slot][column: left, middle, right], rows / columns at CLAMPED addresses
+    auto load_row = [&](int slot, int y) {
+        const size_t o = (size_t)clampi(y, H) * W;
+        const float4 c0 = current[o + xl], c1 = current[o + i], c2 = current[o + xr];
+        const float4 h0 = history[o + xl], h1 = history[o + i], h2 = history[o + xr];
+        c[slot][0] = {c0.x, c0.y, c0.z}; c[slot][1] = {c1.x, c1.y, c1.z}; c[slot][2] = {c2.x, c2.y, c2.z};
+        h[slot][0] = {h0.x, h0.y, h0.z}; h[slot][1] = {h1.x, h1.y, h1.z}; h[slot][2] = {h2.x, h2.y, h2.z};
+    };
+    auto sel = [](bool first, rgb a, rgb b) -> rgb { rgb r; r.x = first ? a.x : b.x; r.y = first ? a.y : b.y; r.z = first ? a.z : b.z; return r; };
+    load_row(0, j0 - 1);
+    load_row(1, j0);
+    const float u = ((float)i + 0.5f) / (float)W;
+    const float ju = u + jitterX;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = j0 + r;
+        if (j >= H) break;                                   // (wave-uniform)
+        const int sa = r % 3, sm = (r + 1) % 3, sb = (r + 2) % 3;          // slots of rows j - 1, j, j + 1
+        load_row(sb, j + 1);
+        const float v = ((float)j + 0.5f) / (float)H;
+        const float jv = v + jitterY;
+        // current = texture(uCurrentFrame, jitteredUV): LINEAR, REPEAT                     :24
+        rgb cur;
+        {
+            const float x = ju * (float)W - 0.5f, y = jv * (float)H - 0.5f;
+            const float fx = floorf(x), fy = floorf(y);
+            const float wx = x - fx, wy = y - fy;
+            const int x0 = (int)fx, y0 = (int)fy;
+            const int dx = x0 - i, dy = y0 - j;
+            const bool inWin = (dx == -1 || dx == 0) && (dy == -1 || dy == 0) && x0 >= 0 && x0 + 1 < W && y0 >= 0 && y0 + 1 < H;
+            const bool left = dx == -1, up = dy == -1;
+            rgb t00 = sel(up, sel(left, c[sa][0], c[sa][1]), sel(left, c[sm][0], c[sm][1]));
+            rgb t10 = sel(up, sel(left, c[sa][1], c[sa][2]), sel(left, c[sm][1], c[sm][2]));
+            rgb t01 = sel(up, sel(left, c[sm][0], c[sm][1]), sel(left, c[sb][0], c[sb][1]));
+            rgb t11 = sel(up, sel(left, c[sm][1], c[sm][2]), sel(left, c[sb][1], c[sb][2]));
+            if (!inWin) {                                    // image border (REPEAT wraps around) or a jitter of a texel and more
+                auto cur_at = [&](int xx, int yy) -> rgb { const float4 q = current[(size_t)wrapi(yy, H) * W + wrapi(xx, W)]; rgb t; t.x = q.x; t.y = q.y; t.z = q.z; return t; };
+                t00 = cur_at(x0, y0); t10 = cur_at(x0 + 1, y0); t01 = cur_at(x0, y0 + 1); t11 = cur_at(x0 + 1, y0 + 1);
+            }
+            const rgb a = lerp3(t00, t10, wx), b = lerp3(t01, t11, wx);
+            cur = lerp3(a, b, wy);
+        }
+        // history = texture(uHistory, TexCoords): LINEAR, CLAMP_TO_EDGE                   :27
+        rgb his;
+        {
+            const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+            const float fx = floorf(x), fy = floorf(y);
+            const float wx = x - fx, wy = y - fy;
+            const int dx = (int)fx - i, dy = (int)fy - j;
+            const bool inWin = (dx == -1 || dx == 0) && (dy == -1 || dy == 0);
+            const bool left = dx == -1, up = dy == -1;
+            // clamp(i + dx) and clamp(i + dx + 1) ARE the window's clamped columns (rows alike)
+            rgb t00 = sel(up, sel(left, h[sa][0], h[sa][1]), sel(left, h[sm][0], h[sm][1]));
+            rgb t10 = sel(up, sel(left, h[sa][1], h[sa][2]), sel(left, h[sm][1], h[sm][2]));
+            rgb t01 = sel(up, sel(left, h[sm][0], h[sm][1]), sel(left, h[sb][0], h[sb][1]));
+            rgb t11 = sel(up, sel(left, h[sm][1], h[sm][2]), sel(left, h[sb][1], h[sb][2]));
+            if (!inWin) {
+                const int x0 = clampi((int)fx, W), x1 = clampi((int)fx + 1, W), y0 = clampi((int)fy, H), y1 = clampi((int)fy + 1, H);
+                auto h_at = [&](int xx, int yy) -> rgb { const float4 q = history[(size_t)yy * W + xx]; rgb t; t.x = q.x; t.y = q.y; t.z = q.z; return t; };
+                t00 = h_at(x0, y0); t10 = h_at(x1, y0); t01 = h_at(x0, y1); t11 = h_at(x1, y1);
+            }
+            const rgb a = lerp3(t00, t10, wx), b = lerp3(t01, t11, wx);
+            his = lerp3(a, b, wy);
+        }
+        // neighbourhood colour box, texelFetch (0 outside the image)                       :30-37
+        rgb mn = cur, mx = cur;
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++) {
+                const int x = i + dx, y = j + dy;
+                const bool inb = x >= 0 && y >= 0 && x < W && y < H;
+                const rgb q = c[dy < 0 ? sa : (dy == 0 ? sm : sb)][dx + 1];
+                const float nx = inb ? q.x : 0.0f, ny = inb ? q.y : 0.0f, nz = inb ? q.z : 0.0f;
+                mn.x = fminf(mn.x, nx); mn.y = fminf(mn.y, ny); mn.z = fminf(mn.z, nz);
+                mx.x = fmaxf(mx.x, nx); mx.y = fmaxf(mx.y, ny); mx.z = fmaxf(mx.z, nz);
+            }
+        }
+        // normal check, NEAREST / REPEAT                                                   :40-45
+        float bf = 0.0f;
+        {
+            const int px = wrapi((int)floorf(u * (float)W), W), py = wrapi((int)floorf(v * (float)H), H);
+            const int cx = wrapi((int)floorf(ju * (float)W), W), cy = wrapi((int)floorf(jv * (float)H), H);
+            const uint2 pn = normal[(size_t)py * W + px];
+            const uint2 cn = (cx == px && cy == py) ? pn : normal[(size_t)cy * W + cx];   // sub-texel jitter: same texel
+            const float pnx = __half2float(__ushort_as_half((unsigned short)(pn.x & 0xffffu))), pny = __half2float(__ushort_as_half((unsigned short)(pn.x >> 16)));
+            const float pnz = __half2float(__ushort_as_half((unsigned short)(pn.y & 0xffffu)));
+            const float cnx = __half2float(__ushort_as_half((unsigned short)(cn.x & 0xffffu))), cny = __half2float(__ushort_as_half((unsigned short)(cn.x >> 16)));
+            const float cnz = __half2float(__ushort_as_half((unsigned short)(cn.y & 0xffffu)));
+            const float d = (pnz * cnz + pny * cny) + pnx * cnx;
+            if (d < 0.9f) bf = blendFactor * 0.2f;
+        }
+        // clipAABB (:13-19) then mix(history, current, blendFactor) (:51)
+        auto resolve = [&](float hh, float cc, float lo, float hi) -> float {
+            const float center = 0.5f * (hi + lo), extents = 0.5f * (hi - lo);
+            float clip = hh - center;
+            clip = fminf(fmaxf(clip, -extents), extents);
+            const float hc = center + clip;
+            return hc + bf * (cc - hc);
+        };
+        out[(size_t)j * W + i] = make_float4(resolve(his.x, cur.x, mn.x, mx.x), resolve(his.y, cur.y, mn.y, mx.y),
+                                             resolve(his.z, cur.z, mn.z, mx.z), 1.0f);
+    }
+}
+
+#ifndef RT_TAA_WINDOW
+#define RT_TAA_WINDOW 1         // 0: the one-texel-per-lane kernel for every launch
+#endif
 hipError_t rt_launch_taa_resolve(const void *current, const void *history, const void *normal, void *out, int W, int H,
                                  float blend, float jx, float jy, hipStream_t s) {
+    // (`out` must not alias the inputs in either form; frames of a few rows keep the one-texel-per-lane kernel)
+    if (RT_TAA_WINDOW && H >= 4 * RT_TAA_ROWS) {
+        dim3 grid((W + 63) / 64, (H + 4 * RT_TAA_ROWS - 1) / (4 * RT_TAA_ROWS));
+        hipLaunchKernelGGL(rt_taa_resolve_rows_kernel, grid, dim3(256), 0, s, (const float4 *)current, (const float4 *)history,
+                           (const uint2 *)normal, (float4 *)out, W, H, blend, jx, jy);
+        return hipGetLastError();
+    }
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY);
     hipLaunchKernelGGL(rt_taa_resolve_kernel, grid, dim3(256), 0, s, (const float4 *)current, (const float4 *)history,
                        (const uint2 *)normal, (float4 *)out, W, H, blend, jx, jy);

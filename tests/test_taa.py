@@ -63,7 +63,11 @@ def test_taa_hip_bit_exact_vs_oracle(tracer, host, oracle):
     for tag in "abc":
         fc, blend, jx, jy = g[f"{tag}_params"]
         cases.append((g[f"{tag}_current"], g[f"{tag}_history"], g[f"{tag}_normal"], float(blend), float(jx), float(jy)))
-    for (w, h, jx, jy) in [(1, 1, 0.0, 0.0), (33, 9, 0.004, 0.0), (7, 70, 0.0, 0.003), (130, 31, 0.02, 0.05), (64, 64, -0.01, 0.3)]:
+    # (frames of >= 32 rows take the register-window kernel: ragged widths and heights that are no multiple of a lane's row run,
+    #  sub-texel jitter of either sign -- taps inside the window --, a texel and more -- taps loaded --, zero jitter)
+    for (w, h, jx, jy) in [(1, 1, 0.0, 0.0), (33, 9, 0.004, 0.0), (7, 70, 0.0, 0.003), (130, 31, 0.02, 0.05), (64, 64, -0.01, 0.3),
+                           (130, 95, 0.003, -0.004), (257, 64, -0.0035, 0.007), (64, 33, 0.0, 0.0), (100, 200, 0.011, 0.0049),
+                           (65, 37, 0.0153, -0.0269), (192, 108, 0.0013, 0.0023)]:
         cur = rng.uniform(0, 4, (h, w, 4)).astype(np.float32)
         his = rng.uniform(0, 4, (h, w, 4)).astype(np.float32)
         nrm = rng.normal(size=(h, w, 4)).astype(np.float16)
