@@ -85,6 +85,7 @@ struct rt_context {
     unsigned *dShadowTab = nullptr;
     size_t capShadowTab = 0;
     bool shadowTabValid = false;
+    bool shadowTabBlocker = false;             // the buffer also holds the blocker-ray tables of the scene's PCSS lights
     std::vector<uint8_t> lastScene;            // the bytes of the current scene (objects, then lights): an identical re-upload is a no-op
     bool stOnePhase = false;                   // RT_ST_BUILD=full: the one-phase builder (every object in every cell; comparison builds only)
     RtShadowTabGeom stGeomSmall = {48, 96, 32}, stGeomLarge = {32, 64, 32};      // <= 32 objects / more (RT_ST_GEOM overrides both); measured: DESIGN.md
@@ -591,8 +592,15 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     c->shadowTabValid = false;
     if (nObj > 0 && nLt > 0 && nObj <= RT_ST_MAX_OBJECTS && nLt <= RT_ST_MAX_LIGHTS) {
         const RtShadowTabGeom &g = nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
-        if ((rc = ensure(c, &c->dShadowTab, &c->capShadowTab, rt_shadowtab_dwords(g, nObj, nLt)))) return rc;
-        HIP_TRY(c, rt_launch_shadow_tables(c->dCompiled, nObj, nLt, c->dShadowTab, g, c->stream, c->stOnePhase));
+        bool pcss = false;            // a PCSS light: the blocker rays get tables of their own (few-object scenes: the PkLightS profile reads them)
+        for (int i = 0; i < nLt && nObj <= 32; i++) {
+            rt_light l;
+            memcpy(&l, (const uint8_t *)lights + (size_t)i * RT_LIGHT_STRIDE, sizeof l);
+            pcss = pcss || l.shadowType == 2;
+        }
+        c->shadowTabBlocker = pcss;
+        if ((rc = ensure(c, &c->dShadowTab, &c->capShadowTab, rt_shadowtab_dwords(g, nObj, nLt, pcss)))) return rc;
+        HIP_TRY(c, rt_launch_shadow_tables(c->dCompiled, nObj, nLt, c->dShadowTab, g, c->stream, c->stOnePhase, pcss));
         c->shadowTabValid = true;
     }
     HIP_TRY(c, hipEventRecord(c->evScene, c->stream));   // foreign streams order behind this (rt_render_to)
@@ -799,7 +807,7 @@ int rt_debug_shadow_tables(rt_context *c, uint32_t *out, size_t capDwords, size_
     if (wordsPerCell) *wordsPerCell = 0;
     if (!c->shadowTabValid) return RT_OK;
     const RtShadowTabGeom &g = c->nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
-    const size_t n = rt_shadowtab_table_dwords(g, c->nObj, c->nLt);      // (the builder's scratch behind the tables is not part of them)
+    const size_t n = rt_shadowtab_table_dwords(g, c->nObj, c->nLt, c->shadowTabBlocker);      // (the builder's scratch behind the tables is not part of them)
     *nDwords = n;
     if (wordsPerCell) *wordsPerCell = rt_shadowtab_words(c->nObj);
     if (!out) return RT_OK;

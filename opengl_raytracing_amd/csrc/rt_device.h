@@ -43,7 +43,7 @@ struct RtDeviceScene {
     const unsigned *shadowTab;
 };
 
-#define RT_ST_HDR_F4 6            // float4 per light header
+#define RT_ST_HDR_F4 7            // float4 per light header
 #define RT_ST_MAX_OBJECTS 256     // 8 dwords per cell
 #define RT_ST_MAX_LIGHTS 64       // (a table is 0.4-6 MB per light)
 // dwords per cell for a scene of nObj objects (the packet kernel's profiles are compiled for exactly these: rt_packet.inc)
@@ -56,16 +56,18 @@ static inline size_t rt_shadowtab_dir_cells(const RtShadowTabGeom &g) {
     const size_t cube = (size_t)6 * g.Kcube * g.Kcube, plan = (size_t)g.Kplan * g.Kplan;
     return cube > plan ? cube : plan;
 }
-// dwords of headers + cells (what the render kernel reads, and rt_debug_shadow_tables returns)
-static inline size_t rt_shadowtab_table_dwords(const RtShadowTabGeom &g, int nObj, int nLt) {
+// dwords of headers + cells (what the render kernel reads, and rt_debug_shadow_tables returns).  `blocker`: the scene has a PCSS
+// light -- a second set of tables, for pcssShadow's blocker rays, follows the first (rt_shadowtab.inc)
+static inline size_t rt_shadowtab_table_dwords(const RtShadowTabGeom &g, int nObj, int nLt, bool blocker) {
     const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
-    return (size_t)nLt * RT_ST_HDR_F4 * 4 + (size_t)nLt * (cube > plan ? cube : plan) * rt_shadowtab_words(nObj) + 4;
+    return (size_t)nLt * RT_ST_HDR_F4 * 4 + (size_t)(blocker ? 2 : 1) * nLt * (cube > plan ? cube : plan) * rt_shadowtab_words(nObj) + 4;
 }
 // ... + the builder's scratch
-static inline size_t rt_shadowtab_dwords(const RtShadowTabGeom &g, int nObj, int nLt) {
-    return rt_shadowtab_table_dwords(g, nObj, nLt) + (size_t)nLt * rt_shadowtab_dir_cells(g) * rt_shadowtab_words(nObj);
+static inline size_t rt_shadowtab_dwords(const RtShadowTabGeom &g, int nObj, int nLt, bool blocker) {
+    return rt_shadowtab_table_dwords(g, nObj, nLt, blocker) + (size_t)(blocker ? 2 : 1) * nLt * rt_shadowtab_dir_cells(g) * rt_shadowtab_words(nObj);
 }
-hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s, bool onePhase = false);
+hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s, bool onePhase = false,
+                                   bool blocker = false);
 
 #define RT_PCF_TAB_N 16      // PCF samples tabulated per directional light (UI range of pcfSamples is 1..16)
 // float4 count of the whole compiled buffer: the staged part (rt_compiled_f4) + per light RT_PCF_TAB_N x 2 float4

@@ -1052,19 +1052,23 @@ hipError_t rt_launch_compile_scene(const uint8_t *dObjects, int nObj, const uint
 #ifndef RT_ST_NMAX
 #define RT_ST_NMAX 8.0f         // lanes whose shading normal is longer take every object (the tables' aim-error bound assumes |N| <= this)
 #endif
-hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s, bool onePhase) {
+hipError_t rt_launch_shadow_tables(const float4 *dCompiled, int nObj, int nLt, unsigned *dTab, const RtShadowTabGeom &g, hipStream_t s, bool onePhase,
+                                   bool blocker) {
     if (nLt <= 0 || nObj <= 0 || nObj > RT_ST_MAX_OBJECTS || nLt > RT_ST_MAX_LIGHTS) return hipSuccess;
     const int NW = rt_shadowtab_words(nObj);
     const size_t cube = (size_t)g.NB * 6 * g.Kcube * g.Kcube, plan = (size_t)g.NB * g.Kplan * g.Kplan + 1;
     hipLaunchKernelGGL(rt_shadowtab_headers_kernel, dim3((unsigned)nLt), dim3(64), 0, s, dCompiled, nObj, nLt, (float4 *)dTab, g.Kcube, g.Kplan,
-                       g.NB, NW, RT_ST_NMAX, (unsigned)(cube > plan ? cube : plan));
-    const size_t maxCells = cube > plan ? cube : plan, dirCells = rt_shadowtab_dir_cells(g), dirBase = rt_shadowtab_table_dwords(g, nObj, nLt);
+                       g.NB, NW, RT_ST_NMAX, (unsigned)(cube > plan ? cube : plan), blocker ? 1 : 0);
+    const size_t maxCells = cube > plan ? cube : plan, dirCells = rt_shadowtab_dir_cells(g), dirBase = rt_shadowtab_table_dwords(g, nObj, nLt, blocker);
     const dim3 gridCells((unsigned)((maxCells + 255) / 256), (unsigned)nLt), gridDir((unsigned)((dirCells + 255) / 256), (unsigned)nLt, (unsigned)NW);
-    if (onePhase) {
-        hipLaunchKernelGGL(rt_shadowtab_build_kernel<0>, gridCells, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, dirBase, dirCells);
-    } else {      // every object per direction cell once, then the per-bin tests for the survivors (rt_shadowtab.inc)
-        hipLaunchKernelGGL(rt_shadowtab_build_kernel<1>, gridDir, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, dirBase, dirCells);
-        hipLaunchKernelGGL(rt_shadowtab_build_kernel<2>, gridCells, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, dirBase, dirCells);
+    for (int b = 0; b < (blocker ? 2 : 1); b++) {        // the PCF tables, then (scenes with a PCSS light) the blocker tables
+        const size_t scratch = dirBase + (size_t)b * nLt * dirCells * NW;
+        if (onePhase) {
+            hipLaunchKernelGGL(rt_shadowtab_build_kernel<0>, gridCells, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, scratch, dirCells, b);
+        } else {      // every object per direction cell once, then the per-bin tests for the survivors (rt_shadowtab.inc)
+            hipLaunchKernelGGL(rt_shadowtab_build_kernel<1>, gridDir, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, scratch, dirCells, b);
+            hipLaunchKernelGGL(rt_shadowtab_build_kernel<2>, gridCells, dim3(256), 0, s, dCompiled, nObj, nLt, (const float4 *)dTab, dTab, NW, scratch, dirCells, b);
+        }
     }
     return hipGetLastError();
 }

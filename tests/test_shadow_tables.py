@@ -38,10 +38,14 @@ def _plane_basis(n):
     return r, f
 
 
-def _lookup(hdr, cells, nw, O, Lpos, ldir, D, nn, n_obj):
+def _lookup(hdr, cells, nw, O, Lpos, ldir, D, nn, n_obj, blocker=False):
     """st_lane_mask (rt_packet.inc) in fp32 for M lanes: -> uint32[M, nw]."""
     M = len(O)
     kind, base, K, NB = (int(hdr[0].view(np.int32)[k]) for k in range(4))
+    if blocker:                      # the light's second table (pcssShadow's blocker rays): same cells, its own base
+        base = int(hdr[6].view(np.int32)[0])
+        if base == 0:
+            kind = 0
     valid = np.zeros(nw, dtype=np.uint32)
     for k in range(nw):
         nb = n_obj - 32 * k
@@ -92,7 +96,7 @@ def _check_scene(tracer, sc, rng, n_points=600):
     assert tab is not None, "rt_set_scene built no shadow tables"
     objs, lts = sc.objects, sc.lights
     n_obj, n_lt = len(objs), len(lts)
-    hdrs = tab[: n_lt * 24].view(F).reshape(n_lt, 6, 4)
+    hdrs = tab[: n_lt * 28].view(F).reshape(n_lt, 7, 4)
     # shading points: on the spheres and on the plane rectangles (finite records only), as the kernel produces them
     fin = np.isfinite(objs["position"]).all(axis=1) & np.isfinite(objs["radius"]) & np.isfinite(objs["normal"]).all(axis=1) & \
         np.isfinite(objs["size"]).all(axis=1) & (objs["type"] <= 1)
@@ -194,10 +198,54 @@ def _check_scene(tracer, sc, rng, n_points=600):
                 stats["hits"] += int(hit.sum())
                 assert not bad.any(), (f"{sc.name}: light {li} (type {ltype}, table kind {kind}) sample {s}: object {j} is hit by "
                                        f"{int(bad.sum())} shading point(s) whose table cell does not list it, e.g. P = {P[np.flatnonzero(bad)[0]]}")
+        # pcssShadow's 16 blocker rays (:409-427) against the light's BLOCKER table
+        if int(lt["shadowType"]) == 2 and int(hdrs[li][6].view(np.int32)[0]) != 0:
+            blane = _lookup(hdrs[li], tab, nw, O32, Lpos, ldir[0].astype(F), D.astype(F), nn.astype(F), n_obj, blocker=True)
+            stats["blocker_mean_bits"] = stats.get("blocker_mean_bits", []) + [float(np.mean([bin(int(x)).count("1") for row in blane for x in row]) * nw)]
+            ss = float(F(lt["lightSize"]) * F(0.1))
+            for sidx in range(16):
+                rr = _halton(sidx, 3) * 2.0 - 1.0
+                jd = ldir + rr * ss + rr * ss
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    jd = jd / np.linalg.norm(jd, axis=1)[:, None]
+                Oo = O32.astype(np.float64)
+                for j in range(n_obj):
+                    o = objs[j]
+                    if o["type"] == 0:
+                        c, r = o["position"].astype(np.float64), float(o["radius"])
+                        oc = Oo - c
+                        a = (jd * jd).sum(1)
+                        b = 2.0 * (oc * jd).sum(1)
+                        cc = (oc * oc).sum(1) - r * r
+                        disc = b * b - 4 * a * cc
+                        with np.errstate(invalid="ignore", divide="ignore"):
+                            t = np.where(disc >= 0, (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a), np.nan)
+                    elif o["type"] == 1:
+                        n = o["normal"].astype(np.float64)
+                        if not np.isfinite(n).all() or not np.isfinite(o["position"]).all():
+                            continue
+                        upv = [0, 0, 1] if abs(n[1]) > 0.9 else [0, 1, 0]
+                        if np.linalg.norm(np.cross(n, upv)) == 0:
+                            continue
+                        r_, f_ = _plane_basis(n)
+                        denom = jd @ n
+                        with np.errstate(invalid="ignore", divide="ignore"):
+                            tt = ((o["position"].astype(np.float64) - Oo) @ n) / denom
+                        lo = Oo + jd * tt[:, None] - o["position"].astype(np.float64)
+                        okp = (np.abs(denom) > 1e-6) & (tt >= 0) & (np.abs(lo @ r_) <= float(o["size"][0]) / 2) & (np.abs(lo @ f_) <= float(o["size"][1]) / 2)
+                        t = np.where(okp, tt, np.nan)
+                    else:
+                        continue
+                    hit = (t > 0) & (t < limit)
+                    bit = (blane[:, j >> 5] >> np.uint32(j & 31)) & np.uint32(1)
+                    bad = hit & (bit == 0)
+                    stats["blocker_hits"] = stats.get("blocker_hits", 0) + int(hit.sum())
+                    assert not bad.any(), (f"{sc.name}: light {li} (type {ltype}) blocker ray {sidx}: object {j} is hit by {int(bad.sum())} "
+                                           f"shading point(s) whose BLOCKER table cell does not list it, e.g. P = {P[np.flatnonzero(bad)[0]]}")
     return stats
 
 
-@pytest.mark.parametrize("cfg", [2, 4, 5])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
 def test_tables_cover_every_hit_of_the_configs_scenes(tracer, host, cfg):
     sc = scenes.make_scene(cfg, host.generate_aabb)
     st = _check_scene(tracer, sc, np.random.default_rng(cfg), n_points=400 if cfg == 5 else 800)
@@ -206,6 +254,10 @@ def test_tables_cover_every_hit_of_the_configs_scenes(tracer, host, cfg):
           f"{st['lanes_all']} of {st['lanes']} lanes take every object; {st['hits']} ray hits checked")
     # selective: a shading point keeps a small part of the scene per light
     assert np.mean(st["cells_mean_bits"]) < 0.5 * len(sc.objects)
+    if cfg == 3:        # PCSS lights: the blocker tables were checked too
+        assert st.get("blocker_hits", 0) > 0
+        print(f"C3: mean candidate bits per lane and light in the BLOCKER tables {np.mean(st['blocker_mean_bits']):.2f} of {len(sc.objects)}; "
+              f"{st['blocker_hits']} blocker-ray hits checked")
 
 
 def test_tables_cover_every_hit_of_fuzzed_scenes(tracer, host):
@@ -247,10 +299,10 @@ def test_two_phase_build_equals_the_one_phase_build(host):
             assert t1 is None
             continue
         assert nw == nw1 and t1.shape == t2.shape
-        nh = len(sc.lights) * 6 * 4
+        nh = len(sc.lights) * 7 * 4
         assert np.array_equal(t1[:nh], t2[:nh]), f"{sc.name}: headers differ"
         for li in range(len(sc.lights)):         # each light's cells: [base, base + nCells * nw) dwords (the rest of the buffer is unused)
-            hdr = t1[li * 24:(li + 1) * 24]
+            hdr = t1[li * 28:(li + 1) * 28]
             kind, base, n_cells = int(hdr[0]), int(hdr[1]), int(hdr[11])        # header ints are stored as raw bits
             if kind == 0:
                 continue
@@ -258,5 +310,11 @@ def test_two_phase_build_equals_the_one_phase_build(host):
             assert not (b & ~a).any(), f"{sc.name} light {li}: the two-phase table lists an object the one-phase table does not"
             cells += a.size
             diff += int((a != b).sum())
+            bbase = int(hdr[24])             # the blocker table of a PCSS light (0: none)
+            if bbase:
+                a, b = t1[bbase:bbase + n_cells * nw], t2[bbase:bbase + n_cells * nw]
+                assert not (b & ~a).any(), f"{sc.name} light {li}: the two-phase BLOCKER table lists an object the one-phase table does not"
+                cells += a.size
+                diff += int((a != b).sum())
     print(f"two-phase vs one-phase: {diff} of {cells} cell words differ")
     assert diff <= cells * 1e-5
