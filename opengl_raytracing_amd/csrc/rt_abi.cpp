@@ -592,8 +592,8 @@ int rt_set_scene(rt_context *c, const void *objects, int nObj, const void *light
     c->shadowTabValid = false;
     if (nObj > 0 && nLt > 0 && nObj <= RT_ST_MAX_OBJECTS && nLt <= RT_ST_MAX_LIGHTS) {
         const RtShadowTabGeom &g = nObj <= 32 ? c->stGeomSmall : c->stGeomLarge;
-        bool pcss = false;            // a PCSS light: the blocker rays get tables of their own (few-object scenes: the PkLightS profile reads them)
-        for (int i = 0; i < nLt && nObj <= 32; i++) {
+        bool pcss = false;            // a PCSS light: its blocker rays get a table of their own (the PCSS kernel instantiations read it)
+        for (int i = 0; i < nLt; i++) {
             rt_light l;
             memcpy(&l, (const uint8_t *)lights + (size_t)i * RT_LIGHT_STRIDE, sizeof l);
             pcss = pcss || l.shadowType == 2;

@@ -1,6 +1,6 @@
 """Build macro variants of the library ON the GPU box and time them at the configs' full sizes in one gpurun call,
 checking every variant's three surfaces against the first variant's bit for bit.
-usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH] [--pcf=N]
+usage: python tools/gpu_try.py "base:" "name:-DRT_X=1 -DRT_Y=2" ... [--cfgs=2,4,5] [--reps=7] [--size=WxH] [--pcf=N] [--pcss=1]
 A spec "name:@path/to/lib.so" takes a library prebuilt in the build container (tools/build_variants.py -> exp/) instead of
 compiling on the box (box time is GPU budget)."""
 import os, re, subprocess, sys, zlib
@@ -22,6 +22,8 @@ if os.environ.get("RT_TRY_CHILD"):
         p = sc.params(width=w, height=h)
         if "pcf" in opt:
             sc.lights["pcfSamples"] = int(opt["pcf"])
+        if "pcss" in opt:                    # every light PCSS (shadowType 2): the PCSS kernel instantiations on any config's scene
+            sc.lights["shadowType"] = 2
         rt.load(sc)
         for _ in range(3):
             rt.render(p); rt.sync()
