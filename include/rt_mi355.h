@@ -225,8 +225,8 @@ int rt_debug_predicted_classes(rt_context *ctx, uint8_t *out, int cap, int *nTil
  * per light 28 dwords of header -- (kind, base dword, K, NB) (invBinW, binMax, wlo, nmax^2) (pmin, qmin, invCell, cells)
  * (T0, eta) (B0, nmax) (light position or direction, binW) (base dword of the light's BLOCKER table or 0, its eta, -, -);
  * kind 0 no table, 1 cube map x distance bins (point / area), 2 planar grid x depth bins (directional) -- followed by the
- * cells, *wordsPerCell dwords each, bit i = object i may occlude a PCF ray of a shading point that reads the cell; scenes of
- * <= 32 objects with a PCSS light: a second table per such light, same cells, for pcssShadow's 16 blocker rays
+ * cells, *wordsPerCell dwords each, bit i = object i may occlude a PCF ray of a shading point that reads the cell; scenes
+ * with a PCSS light: a second table per such light, same cells, for pcssShadow's 16 blocker rays
  * (raytracingCs.glsl:409-427).  out == NULL only queries *nDwords.  Test hook
  * (tests/test_shadow_tables.py checks the tables against brute-force rays); synchronises.  No reference counterpart. */
 int rt_debug_shadow_tables(rt_context *ctx, uint32_t *out, size_t capDwords, size_t *nDwords, int *wordsPerCell);
