@@ -20,9 +20,13 @@ HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_packet.inc"
 
 # -ffp-contract=off: the reference's GL never fuses a*b+c; IEEE divide and
 # sqrt are hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
+# -fno-slp-vectorize: the SLP vectorizer pairs adjacent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32; in these kernels
+# the even-aligned register pairs and the moves that feed them cost more than the packed issue saves (measured, same run,
+# bit-identical: C2 0.322 -> 0.312 ms, C4 4.65 -> 4.17, C5 24.8 -> 20.9, SSAO 385 -> 364 us; bloom's explicitly packed arithmetic
+# and the TAA resolve unchanged).
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-rdc",
+    "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-rdc", "-fno-slp-vectorize",
     "-Wall", "-Wextra", "-Wno-unused-parameter",
 ]
 

@@ -361,9 +361,8 @@ __device__ __forceinline__ v3 compute_pbr_t(const Mat &m, v3 N, v3 V, v3 L, v3 H
 #define RT_FAST_DIV 1           // 0: every general division of the path by the compiler's IEEE sequence
 #endif
 // `live`: lanes whose result is used (the packet kernel calls this with the whole wave; a dead lane's stale or NaN operands
-// must not send the wave through the IEEE instantiation).  FASTDIV is a profile constant of the packet kernel: measured,
-// bit-identical, C4 4.78 -> 4.66 ms and C5 25.3 -> 24.9 ms with it, but C2 0.347 -> 0.367 and C3 3.39 -> 3.44 (the LIGHT
-// profiles' register allocation, not the fallback: masking it with `live` changed nothing) -- so the many-object profiles use it.
+// must not send the wave through the IEEE instantiation).  FASTDIV is a profile constant of the packet kernel (rt_packet.inc:
+// RT_LIGHT_FAST_PBR / RT_HEAVY_FAST_PBR carry the measurements); every shipped profile uses it.
 template <bool FASTDIV = false>
 __device__ __forceinline__ v3 compute_pbr(const Mat &m, v3 N, v3 V, v3 L, v3 H, v3 radiance, bool live = true) {
     bool ok;
